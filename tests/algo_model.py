@@ -1,0 +1,180 @@
+"""Executable numpy model of the algorithm the HIP kernel implements (csrc/vsmpc_kernels.hip).
+
+Test helper only: it documents the kernel's phases in plain array code and lets the CPU test
+suite check the *algorithm* (condensing recursion, augmented Cholesky, Schur-complement box QP,
+back-substitution, forward simulation) against the oracle without a GPU.  It is NOT a product
+path and nothing outside tests/ imports it.
+
+Phases (same names as the kernel):
+  P0 linearise      A, Bj, Bt, c from the input record
+  P1 condense       S_{k+1} = (I + dt_k A) S_k + dt_k E_k, per column in registers; Y_k = sqrt(Q) S_k[W]
+                    C = sum_k Y_k^T Y_k over 128 padded columns (MFMA f64 16x16x4 on the GPU)
+                    column order: [U_0..U_{H-1} | v_1..v_{nvb-1} | v_0 | affine | pad]
+  P2 augment        M = C + R ; row `NZ` of M holds the condensed gradient
+  P3 cholesky       first NZ pivots of the padded matrix; row NZ becomes (L^-1 g)^T
+  P4 box QP on v    S = L22 L22^T, s = L22 (L^-1 g)_v ; block principal pivoting
+  P5 back-subst     U = L11^-T (y_U - L21^T v)
+  P6 simulate       X_{k+1} = X_k + dt_k (A X_k + Bj U + Bt v + c)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+W_ROWS = list(range(0, 12)) + list(range(20, 26))  # the 18 weighted state rows (costsVSMPC.cpp:78-93)
+
+
+def column_maps(cfg):
+    """Internal input ordering [U | v_1..v_{nvb-1} | v_0] -> (kind, block, component)."""
+    H, nvb = cfg.control_horizon, cfg.n_vblocks
+    cols = [("U", j, q) for j in range(H) for q in range(8)]
+    cols += [("v", b, i) for b in range(1, nvb) for i in range(4)]
+    cols += [("v", 0, i) for i in range(4)]
+    return cols
+
+
+def solve_model(cfg, oracle, inp, max_bpp_iter=60):
+    """`oracle` is the oracle module (for linearize/dt_schedule helpers that restate the reference);
+    everything downstream of (A, Bj, Bt, c) is the kernel's own algorithm."""
+    N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
+    nvb = cfg.n_vblocks
+    NU, NV = 8 * H, 4 * nvb
+    NZ = NU + NV
+    NP = ((NZ + 1 + 15) // 16) * 16
+    A, Bj, Bt, c = oracle.linearize(cfg, inp)
+    dts = oracle.dt_schedule(cfg)
+    qd = oracle.state_weight(cfg)
+    sq = np.sqrt(qd[W_ROWS])
+    cols = column_maps(cfg)
+    vmin, vmax = oracle.throttle_bounds(cfg)
+    vprev = np.array([oracle.v_of_throttle(inp[oracle.IN_UPREV + i]) for i in range(4)])
+    hold = inp[oracle.IN_HOLD] != 0.0
+    xref_win = inp[oracle.IN_XREF:oracle.IN_XREF + 12 * cfg.n_ref_cols].reshape(cfg.n_ref_cols, 12)
+
+    # ---- P1 condense
+    S = np.zeros((26, NP))
+    S[:, NZ] = inp[0:26]  # affine column starts at x0
+    C = np.zeros((NP, NP))
+    for k in range(N):  # stage k -> node k+1
+        dt = dts[k]
+        jb = oracle.joint_block_of_stage(cfg, k)
+        tb = oracle.throttle_block_of_stage(cfg, k)
+        E = np.zeros((26, NP))
+        for ci, (kind, blk, comp) in enumerate(cols):
+            if kind == "U" and blk == jb:
+                E[:, ci] = Bj[:, comp]
+            if kind == "v" and blk == tb:
+                E[:, ci] = Bt[:, comp]
+        E[:, NZ] = c
+        S = S + dt * (A @ S + E)
+        col = 0 if k < nS else k - nS
+        xr = np.zeros(26)
+        xr[0:12] = xref_win[col]
+        Sa = S.copy()
+        Sa[:, NZ] -= xr
+        Y = sq[:, None] * Sa[W_ROWS, :]
+        C += Y.T @ Y
+
+    # ---- P2 augment with R and the input-cost gradient
+    M = C.copy()
+    gz = np.zeros(NZ)
+    wj = np.asarray(cfg.w_delta_joint) + cfg.w_reg_joint_pos
+    for ci, (kind, blk, comp) in enumerate(cols):
+        if kind == "U":
+            M[ci, ci] += wj[comp]
+            gz[ci] = cfg.w_reg_joint_pos * inp[oracle.IN_QERR + comp]
+    vidx = {(blk, comp): ci for ci, (kind, blk, comp) in enumerate(cols) if kind == "v"}
+    for i in range(4):
+        for b in range(nvb - 1):
+            a_, b_ = vidx[(b, i)], vidx[(b + 1, i)]
+            M[a_, a_] += cfg.w_throttle
+            M[b_, b_] += cfg.w_throttle
+            M[a_, b_] -= cfg.w_throttle
+            M[b_, a_] -= cfg.w_throttle
+        M[vidx[(0, i)], vidx[(0, i)]] += cfg.w_initial_throttle
+        gz[vidx[(0, i)]] += -cfg.w_initial_throttle * vprev[i]
+    M[NZ, :NZ] += gz
+    M[:NZ, NZ] += gz
+
+    # ---- P3 Cholesky of the leading NZ x NZ block; rows >= NZ are carried along (TRSM only)
+    Lf = np.tril(M)
+    for j in range(NZ):
+        d = Lf[j, j]
+        if not d > 0:
+            return None, 3, 0
+        inv = 1.0 / np.sqrt(d)
+        Lf[j:, j] *= inv
+        Lf[j, j] = d * inv
+        for k2 in range(j + 1, NZ + 1):
+            Lf[k2:, k2] -= Lf[k2:, j] * Lf[k2, j]
+    Lm = Lf[:NZ, :NZ]
+    ghat = Lf[NZ, :NZ]          # = L^-1 g
+    y = -ghat
+
+    # ---- P4 box QP on the throttle block via the Schur complement
+    L22 = Lm[NU:, NU:]
+    Sv = L22 @ L22.T
+    sv = L22 @ ghat[NU:]
+    lo = np.full(NV, vmin)
+    hi = np.full(NV, vmax)
+    fixed = np.zeros(NV, dtype=bool)
+    if hold:
+        lo[NV - 4:] = vprev
+        hi[NV - 4:] = vprev
+        fixed[NV - 4:] = True
+    state = np.zeros(NV, dtype=int)
+    state[fixed] = -1
+    v = np.zeros(NV)
+    best, patience, status, iters = NV + 1, 3, 2, 0
+    for it in range(max_bpp_iter):
+        iters = it + 1
+        F = state == 0
+        v = np.where(state == -1, lo, np.where(state == 1, hi, 0.0))
+        # masked system: identity on bound rows (what the single-wave kernel factorises)
+        Sm = np.where(np.outer(F, F), Sv, 0.0) + np.diag((~F).astype(float))
+        rhs = np.where(F, -(sv + Sv @ np.where(F, 0.0, v)), v)
+        v = np.linalg.solve(Sm, rhs)
+        grad = Sv @ v + sv
+        tolv = 1e-12 * (1.0 + np.abs(v))
+        gtol = 1e-10 * (1.0 + np.abs(sv).max())
+        vlo = F & (v < lo - tolv)
+        vhi = F & (v > hi + tolv)
+        rlo = (state == -1) & ~fixed & (grad < -gtol)
+        rhi = (state == 1) & ~fixed & (grad > gtol)
+        inf = vlo | vhi | rlo | rhi
+        ninf = int(inf.sum())
+        if ninf == 0:
+            status = 1
+            break
+        if ninf < best:
+            best, patience = ninf, 3
+            pick = inf
+        elif patience > 0:
+            patience -= 1
+            pick = inf
+        else:
+            pick = np.zeros(NV, dtype=bool)
+            pick[np.nonzero(inf)[0].max()] = True
+        state[pick & vlo] = -1
+        state[pick & vhi] = 1
+        state[pick & (rlo | rhi)] = 0
+
+    # ---- P5 back-substitution for the joints
+    L11, L21 = Lm[:NU, :NU], Lm[NU:, :NU]
+    U = np.linalg.solve(L11.T, y[:NU] - L21.T @ v)
+    z = np.concatenate([U, v])
+
+    # ---- P6 forward simulation, output in the reference's variable order
+    x = np.zeros(cfg.n_var)
+    X = inp[0:26].copy()
+    x[0:26] = X
+    vref = np.zeros(NV)  # reference order v_0..v_{nvb-1}
+    vref[0:4] = v[NV - 4:]
+    vref[4:] = v[:NV - 4]
+    for k in range(N):
+        jb = oracle.joint_block_of_stage(cfg, k)
+        tb = oracle.throttle_block_of_stage(cfg, k)
+        X = X + dts[k] * (A @ X + Bj @ U[8 * jb:8 * jb + 8] + Bt @ vref[4 * tb:4 * tb + 4] + c)
+        x[26 * (k + 1):26 * (k + 2)] = X
+    x[cfg.off_joints:cfg.off_joints + NU] = U
+    x[cfg.off_throttle:cfg.off_throttle + NV] = vref
+    return x, status, iters
