@@ -1,0 +1,169 @@
+/*
+ * vsmpc.h — C-ABI of the MI355X-native batched multi-rate ("variable sampling") MPC solve path.
+ *
+ * Drop-in boundary for ONE hot path of ami-iit/paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub:
+ * the per-tick  IMPCProblem::update() + VariableSamplingMPC::solveMPC()  pair
+ *   (momentum-based-linear-mpc-lib/src/IMPCProblem/IMPCProblem.cpp:150-298,
+ *    momentum-based-linear-mpc-lib/src/variableSamplingMPC/variableSamplingMPC.cpp:88-112),
+ * i.e. linearise -> variable-sampling QP assembly -> QP solve -> first-move extraction, with a batch
+ * axis over independent MPC instances added.  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/src/flight-controller/).  INTEGRATION.md shows the reference-side binding.
+ *
+ * Threading: one handle per host thread / HIP stream; a handle is not thread-safe, distinct handles
+ * are independent (the reference object is single-threaded and stateful too).
+ * Errors: int return, 0 = VSMPC_OK, negative = API/HIP error (never throws, never aborts), plus a
+ * per-instance status array mirroring the OsqpEigen::Status values the reference distinguishes
+ * (IMPCProblem.cpp:285-294): the caller applies "consume only if Solved" (variableSamplingMPC.cpp:91).
+ */
+#ifndef VSMPC_H
+#define VSMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- sizes fixed by the reference (variableSamplingMPC/VSconstant.h:6-16) ---- */
+#define VSMPC_N_STATES 26
+#define VSMPC_N_JOINTS 8
+#define VSMPC_N_THRUSTS 4
+
+/* ---- return codes ---- */
+#define VSMPC_OK 0
+#define VSMPC_ERR_INVALID_ARG (-1)
+#define VSMPC_ERR_UNSUPPORTED_CONFIG (-2)
+#define VSMPC_ERR_BATCH_TOO_LARGE (-3)
+#define VSMPC_ERR_HIP (-4)
+#define VSMPC_ERR_ALLOC (-5)
+
+/* ---- per-instance status (IMPCProblem.cpp:285-294) ---- */
+#define VSMPC_STATUS_SOLVED 1        /* exact optimum found: OsqpEigen::Status::Solved          */
+#define VSMPC_STATUS_MAX_ITER 2      /* active-set iteration cap hit: ...::MaxIterReached        */
+#define VSMPC_STATUS_NUMERICAL 3     /* non-positive pivot / non-finite data: ...::NonCvx/error  */
+
+/*
+ * Configuration = the keys of group VS_MPC_CONFIG (src/config/vs_mcp_config.xml:7-43) that the path
+ * reads (variableSamplingMPC.cpp:24-38, constraintsVSMPC.cpp:25-51,295-322, costsVSMPC.cpp:29-69,
+ * 326-361,445-459,516-535).  XML/TOML parsing stays on the caller's side.
+ */
+typedef struct vsmpc_config {
+    int n_iter;            /* nIter                */
+    int n_iter_small;      /* nIterSmall           */
+    int control_horizon;   /* controlHorizon       */
+    int use_jet_dynamic;   /* useJetDynamic        */
+    double period_mpc;     /* periodMPC            */
+    double period_small;   /* periodMPCSmallSteps  */
+    double period_large;   /* periodMPCLargeSteps  */
+    double w_com_pos[3];       /* weightCoMPos      */
+    double w_com_pos_err[3];   /* weightCoMPosError */
+    double w_lin_mom[3];       /* weightLinMom      */
+    double w_rpy[3];           /* weightRPY         */
+    double w_rpy_err[3];       /* weightRPYError    */
+    double w_ang_mom[3];       /* weightAngMom      */
+    double w_delta_joint[8];   /* weightDeltaJoint  */
+    double w_throttle;         /* weightThrottle    */
+    double w_initial_throttle; /* weightInitialThrottle */
+    double w_reg_joint_pos;    /* weightRegularizationJointPos */
+    double throttle_min;       /* throttleMin (percent) */
+    double throttle_max;       /* throttleMax (percent) */
+} vsmpc_config;
+
+/*
+ * Per-instance input record: `vsmpc_input_doubles()` doubles, array-of-records, C-contiguous
+ * ([batch][n_in]).  It is the data the reference's update() pulls out of QPInput/Robot each tick
+ * (utils/include/QPInput.h:12-124; consumers cited per field).  Offsets in doubles:
+ */
+#define VSMPC_IN_X0 0         /* 26 measured state X0: CoM, h_lin(body), unwrapped RPY, h_ang(body), T, Tdot,
+                                    CoM - posCoMReference, rpy - RPYReference (constraintsVSMPC.cpp:206-230) */
+#define VSMPC_IN_MASS 26      /*  1 Robot::getTotalMass (a float in the reference, utils/include/Robot.h:338) */
+#define VSMPC_IN_WRB 27       /*  9 base rotation wR_b, row-major (systemDynamicsVSMPC.cpp:107,324)            */
+#define VSMPC_IN_OMEGA 36     /*  3 omega_B = wR_b^T * base angular velocity (systemDynamicsVSMPC.cpp:108,325) */
+#define VSMPC_IN_ALPHA 39     /*  1 alpha_gravity of this tick (systemDynamicsVSMPC.cpp:308)                   */
+#define VSMPC_IN_GRAV 40      /*  3 Robot::getGravity (systemDynamicsVSMPC.cpp:309)                            */
+#define VSMPC_IN_AMOM 43      /* 24 Robot::getMatrixAmomJets(true), 6x4 row-major (:93,:304)                   */
+#define VSMPC_IN_LLIN 67      /* 24 Lambda_lin,B 3x8 row-major (systemDynamicsVSMPC.cpp:321-350)               */
+#define VSMPC_IN_LANG 91      /* 24 Lambda_ang,B 3x8 row-major (systemDynamicsVSMPC.cpp:159-206)               */
+#define VSMPC_IN_INERTIA 115  /*  9 I_G 3x3 row-major (systemDynamicsVSMPC.cpp:128-130)                        */
+#define VSMPC_IN_RPY 124      /*  3 base RPY used for W^-1 (systemDynamicsVSMPC.cpp:132-147)                   */
+#define VSMPC_IN_PREF 127     /*  3 QPInput::getPosCoMReference (systemDynamicsVSMPC.cpp:316)                  */
+#define VSMPC_IN_RPYINIT 130  /*  3 configure-time RPY m_rpyInit (systemDynamicsVSMPC.cpp:67,100)              */
+#define VSMPC_IN_T0 133       /*  4 linearisation thrust (systemDynamicsVSMPC.cpp:401-409)                     */
+#define VSMPC_IN_TD0 137      /*  4 linearisation thrust rate                                                  */
+#define VSMPC_IN_UPREV 141    /*  4 QPInput::getThrottleMPC, percent (systemDynamicsVSMPC.cpp:411)             */
+#define VSMPC_IN_TDES 145     /*  4 QPInput::getThrustDesMPC (systemDynamicsVSMPC.cpp:415)                     */
+#define VSMPC_IN_TDDES 149    /*  4 QPInput::getThrustDotDesMPC                                                */
+#define VSMPC_IN_QERR 153     /*  8 q_cmd,sel - q_ref0 (costsVSMPC.cpp:574-589)                                */
+#define VSMPC_IN_HOLD 161     /*  1 != 0 when the 20-tick hold pins v0 this tick (constraintsVSMPC.cpp:351)    */
+#define VSMPC_IN_XREF 162     /* 12*(nIter-nIterSmall+1): reference window, column-major xref[col*12+row],
+                                    rows = CoM, h_lin, RPY, h_ang (costsVSMPC.cpp:96-99,183-264)               */
+
+/* First-move block written per instance (variableSamplingMPC.cpp:99-102,138-151), 24 doubles. */
+#define VSMPC_FM_DQ 0          /* 8 joint-position increments  x[off_joints .. +8]             */
+#define VSMPC_FM_V0 8          /* 4 warped throttle v0         x[off_throttle .. +4]           */
+#define VSMPC_FM_THROTTLE 12   /* 4 throttle percent, JetModel::destandardizeThrottle_u2T(v0)  */
+#define VSMPC_FM_THRUST 16     /* 4 thrust reference    = node 1 thrust  X1[12:16]             */
+#define VSMPC_FM_THRUSTDOT 20  /* 4 thrust-rate reference = node 1      X1[16:20]              */
+#define VSMPC_FM_SIZE 24
+
+typedef struct vsmpc_handle vsmpc_handle;
+
+/* Replaces IMPCProblem::configure (IMPCProblem.cpp:3-148) + VariableSamplingMPC::setCostAndConstraints
+ * (variableSamplingMPC.cpp:7-86): validates the configuration, selects the kernel instantiation and
+ * allocates device buffers for `max_batch` instances on HIP device `device`.  No allocation happens
+ * in any later call. */
+int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handle** out);
+void vsmpc_destroy(vsmpc_handle* h);
+
+/* IMPCProblem::getNOptimizationVariables / getNConstraints (IMPCProblem.h:71-78) and record sizes. */
+int vsmpc_num_variables(const vsmpc_handle* h);    /* nVar  = 26(N+1)+8H+4(H-nS+1)  (588) */
+int vsmpc_num_constraints(const vsmpc_handle* h);  /* nCon  = 26(N+1)+4(N-nS+1)     (512) */
+int vsmpc_input_doubles(const vsmpc_handle* h);    /* n_in  = 162+12(N-nS+1)        (294) */
+int vsmpc_max_batch(const vsmpc_handle* h);
+
+/* Replaces update()+solveMPC() for `batch` independent instances (variable_sampling_mpc.py:111-112).
+ * Host buffers: in[batch*n_in]; x[batch*nVar] primal in the REFERENCE variable order
+ * [X0..XN | U0..U_{H-1} | v0..v_{H-nS}]; first_move[batch*24]; status[batch]; iters[batch] (active-set
+ * iterations).  x, first_move, iters may be NULL.  `stream` is a hipStream_t (NULL = default stream);
+ * the call returns after the results are in the host buffers. */
+int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, double* first_move,
+                      int* status, int* iters, void* stream);
+
+/* Same, all pointers are DEVICE pointers and the call only enqueues work on `stream` (no copies,
+ * no synchronisation): the form a resident batch driver uses. */
+int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, double* d_x,
+                             double* d_first_move, int* d_status, int* d_iters, void* stream);
+
+/* Parity split of the path: only the per-tick linearisation + discretisation, i.e.
+ * SystemDynamicVS::updateDynamicMatrices/getAMatrix/getBJointsMatrix/getBThrottleMatrix/getCVector
+ * (systemDynamicsVSMPC.cpp:495-585) and the dt schedule of constraintsVSMPC.cpp:45-51,78-84.
+ * Host buffers, row-major per instance: A[batch*676], Bj[batch*208], Bt[batch*104], c[batch*26],
+ * dt[nIter] (same for every instance). */
+int vsmpc_linearize_batch(vsmpc_handle* h, const double* in, int batch, double* A, double* Bj,
+                          double* Bt, double* c, double* dt);
+
+/* Debug/parity: the reference-ordered dense QP of ONE instance, assembled on the host from the
+ * DEVICE linearisation exactly as IMPCProblem::update stacks it (IMPCProblem.cpp:150-194):
+ * H[nVar*nVar], g[nVar], Ac[nCon*nVar] (row-major), lo[nCon], hi[nCon]. */
+int vsmpc_assemble_dense(vsmpc_handle* h, const double* in_one, double* H, double* g, double* Ac,
+                         double* lo, double* hi);
+
+/* Debug/parity: condensed problem of ONE instance after the device condensing + factorisation
+ * phases.  M[np*np] row-major lower triangle of the augmented condensed Hessian (np =
+ * vsmpc_condensed_dim(h); row NZ holds the condensed gradient), L likewise after the Cholesky. */
+int vsmpc_condensed_dim(const vsmpc_handle* h);
+int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, double* Lfac);
+
+/* Average device time per launch of the solve kernel over the launches enqueued between
+ * vsmpc_timing_begin and vsmpc_timing_end on the handle's stream, measured with HIP events on the
+ * stream the kernel is launched on.  Returns milliseconds through *ms_per_launch. */
+int vsmpc_timing_begin(vsmpc_handle* h, void* stream);
+int vsmpc_timing_end(vsmpc_handle* h, void* stream, int launches, float* ms_per_launch);
+
+const char* vsmpc_strerror(int code);
+const char* vsmpc_kernel_name(const vsmpc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSMPC_H */

@@ -1,0 +1,348 @@
+// C-ABI of include/vsmpc.h: handle management, host<->device staging, dense-QP debug assembly.
+// No compute fallback lives here: every numeric result comes from the HIP kernels.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "vsmpc_launch.hpp"
+
+using namespace vsmpc;
+
+struct vsmpc_handle {
+    vsmpc_config cfg;
+    DevCfg dev;
+    int variant;
+    int device;
+    int max_batch;
+    int n_var, n_con, n_in, n_p;
+    // device staging buffers for the host-pointer entry points
+    double* d_in;
+    double* d_x;
+    double* d_fm;
+    int* d_status;
+    int* d_iters;
+    double* d_lin;  // A | Bj | Bt | c for max_batch instances
+    double* d_dbg;  // M | L for one instance
+    hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+thread_local char g_hip_msg[256] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_hip_msg, sizeof(g_hip_msg), "HIP error in %s: %s", what, hipGetErrorString(e));
+    return VSMPC_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+// dt schedule: constraintsVSMPC.cpp:45-51 (beta1, beta2), :78-84, :156-159
+void fill_dt(const vsmpc_config& c, double* dt) {
+    const double nS = double(c.n_iter_small);
+    const double beta2 = (c.period_large - nS * c.period_small) / (nS * (nS - 1.0));
+    const double beta1 = c.period_small - beta2;
+    auto warp = [&](double t) { return beta1 * t + beta2 * t * t; };
+    for (int i = 0; i < c.n_iter; ++i)
+        dt[i] = i < c.n_iter_small ? warp(double(i + 1)) - warp(double(i)) : c.period_large;
+}
+
+void fill_devcfg(const vsmpc_config& c, DevCfg& d) {
+    memset(&d, 0, sizeof(d));
+    fill_dt(c, d.dt);
+    // diagonal of Q on the weighted rows (costsVSMPC.cpp:78-93): p, h_lin, rpy, h_ang | e_pos, e_rpy
+    const double q[NWROWS] = {c.w_com_pos[0], c.w_com_pos[1], c.w_com_pos[2], c.w_lin_mom[0], c.w_lin_mom[1],
+                              c.w_lin_mom[2], c.w_rpy[0], c.w_rpy[1], c.w_rpy[2], c.w_ang_mom[0],
+                              c.w_ang_mom[1], c.w_ang_mom[2], c.w_com_pos_err[0], c.w_com_pos_err[1],
+                              c.w_com_pos_err[2], c.w_rpy_err[0], c.w_rpy_err[1], c.w_rpy_err[2]};
+    for (int i = 0; i < NWROWS; ++i) d.sq[i] = std::sqrt(q[i]);
+    for (int i = 0; i < NJ; ++i) d.wj[i] = c.w_delta_joint[i] + c.w_reg_joint_pos;
+    d.w_reg = c.w_reg_joint_pos;
+    d.w_thr = c.w_throttle;
+    d.w_init = c.w_initial_throttle;
+    d.vmin = Jet::v_of_throttle(c.throttle_min);  // constraintsVSMPC.cpp:329-332
+    d.vmax = Jet::v_of_throttle(c.throttle_max);
+    d.use_jet = c.use_jet_dynamic ? 1 : 0;
+    d.max_as_iter = 64;
+}
+
+bool config_valid(const vsmpc_config& c) {
+    if (c.n_iter < 2 || c.n_iter > MAX_STAGES) return false;
+    if (c.n_iter_small < 2 || c.n_iter_small > c.control_horizon) return false;
+    if (c.control_horizon > c.n_iter) return false;
+    if (!(c.period_small > 0.0) || !(c.period_large > 0.0)) return false;
+    const double q[] = {c.w_com_pos[0], c.w_com_pos[1], c.w_com_pos[2], c.w_lin_mom[0], c.w_lin_mom[1],
+                        c.w_lin_mom[2], c.w_rpy[0], c.w_rpy[1], c.w_rpy[2], c.w_ang_mom[0], c.w_ang_mom[1],
+                        c.w_ang_mom[2], c.w_com_pos_err[0], c.w_com_pos_err[1], c.w_com_pos_err[2],
+                        c.w_rpy_err[0], c.w_rpy_err[1], c.w_rpy_err[2], c.w_throttle, c.w_initial_throttle,
+                        c.w_reg_joint_pos};
+    for (double v : q)
+        if (!(v >= 0.0)) return false;
+    for (int i = 0; i < NJ; ++i)
+        if (!(c.w_delta_joint[i] + c.w_reg_joint_pos > 0.0)) return false;  // condensed Hessian must stay PD
+    if (!(c.w_initial_throttle > 0.0)) return false;
+    if (!(c.throttle_max > c.throttle_min)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handle** out) {
+    if (cfg == nullptr || out == nullptr || max_batch <= 0) return VSMPC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!config_valid(*cfg)) return VSMPC_ERR_INVALID_ARG;
+    const int variant = select_variant(cfg->n_iter, cfg->n_iter_small, cfg->control_horizon);
+    if (variant == VARIANT_NONE) return VSMPC_ERR_UNSUPPORTED_CONFIG;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(device));
+
+    vsmpc_handle* h = new (std::nothrow) vsmpc_handle();
+    if (h == nullptr) return VSMPC_ERR_ALLOC;
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    fill_devcfg(*cfg, h->dev);
+    h->variant = variant;
+    h->device = device;
+    h->max_batch = max_batch;
+    const int N = cfg->n_iter, nS = cfg->n_iter_small, H = cfg->control_horizon;
+    h->n_var = NX * (N + 1) + NJ * H + NTH * (H - nS + 1);
+    h->n_con = NX * (N + 1) + NTH * (N - nS + 1);
+    h->n_in = VSMPC_IN_XREF + 12 * (N - nS + 1);
+    h->n_p = variant_condensed_dim(variant);
+
+    const size_t B = size_t(max_batch);
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&h->d_in, B * h->n_in * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_x, B * h->n_var * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_fm, B * VSMPC_FM_SIZE * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_status, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->d_iters, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&h->d_lin, B * (NX * NX + NX * NJ + NX * NTH + NX) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_dbg, size_t(2) * h->n_p * h->n_p * sizeof(double));
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        vsmpc_destroy(h);
+        return e == hipErrorOutOfMemory ? VSMPC_ERR_ALLOC : hip_fail(e, "vsmpc_create");
+    }
+    *out = h;
+    return VSMPC_OK;
+}
+
+void vsmpc_destroy(vsmpc_handle* h) {
+    if (h == nullptr) return;
+    (void)hipSetDevice(h->device);
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->d_x) (void)hipFree(h->d_x);
+    if (h->d_fm) (void)hipFree(h->d_fm);
+    if (h->d_status) (void)hipFree(h->d_status);
+    if (h->d_iters) (void)hipFree(h->d_iters);
+    if (h->d_lin) (void)hipFree(h->d_lin);
+    if (h->d_dbg) (void)hipFree(h->d_dbg);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int vsmpc_num_variables(const vsmpc_handle* h) { return h ? h->n_var : VSMPC_ERR_INVALID_ARG; }
+int vsmpc_num_constraints(const vsmpc_handle* h) { return h ? h->n_con : VSMPC_ERR_INVALID_ARG; }
+int vsmpc_input_doubles(const vsmpc_handle* h) { return h ? h->n_in : VSMPC_ERR_INVALID_ARG; }
+int vsmpc_max_batch(const vsmpc_handle* h) { return h ? h->max_batch : VSMPC_ERR_INVALID_ARG; }
+int vsmpc_condensed_dim(const vsmpc_handle* h) { return h ? h->n_p : VSMPC_ERR_INVALID_ARG; }
+const char* vsmpc_kernel_name(const vsmpc_handle* h) { return h ? variant_kernel_name(h->variant) : "none"; }
+
+int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, double* d_x, double* d_first_move,
+                             int* d_status, int* d_iters, void* stream) {
+    if (h == nullptr || d_in == nullptr || d_status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch == 0) return VSMPC_OK;
+    HIP_TRY(launch_solve(h->variant, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
+                         static_cast<hipStream_t>(stream)));
+    return VSMPC_OK;
+}
+
+int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, double* first_move, int* status,
+                      int* iters, void* stream) {
+    if (h == nullptr || in == nullptr || status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
+    if (batch == 0) return VSMPC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = size_t(batch);
+    HIP_TRY(hipMemcpyAsync(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+                         nullptr, s));
+    if (x) HIP_TRY(hipMemcpyAsync(x, h->d_x, B * h->n_var * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (first_move)
+        HIP_TRY(hipMemcpyAsync(first_move, h->d_fm, B * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(status, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VSMPC_OK;
+}
+
+int vsmpc_linearize_batch(vsmpc_handle* h, const double* in, int batch, double* A, double* Bj, double* Bt,
+                          double* c, double* dt) {
+    if (h == nullptr || in == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
+    if (dt) fill_dt(h->cfg, dt);
+    if (batch == 0) return VSMPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t B = size_t(batch);
+    double* dA = h->d_lin;
+    double* dBj = dA + size_t(h->max_batch) * NX * NX;
+    double* dBt = dBj + size_t(h->max_batch) * NX * NJ;
+    double* dC = dBt + size_t(h->max_batch) * NX * NTH;
+    HIP_TRY(hipMemcpy(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(launch_linearize(h->variant, h->dev, h->d_in, batch, dA, dBj, dBt, dC, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (A) HIP_TRY(hipMemcpy(A, dA, B * NX * NX * sizeof(double), hipMemcpyDeviceToHost));
+    if (Bj) HIP_TRY(hipMemcpy(Bj, dBj, B * NX * NJ * sizeof(double), hipMemcpyDeviceToHost));
+    if (Bt) HIP_TRY(hipMemcpy(Bt, dBt, B * NX * NTH * sizeof(double), hipMemcpyDeviceToHost));
+    if (c) HIP_TRY(hipMemcpy(c, dC, B * NX * sizeof(double), hipMemcpyDeviceToHost));
+    return VSMPC_OK;
+}
+
+// Stacks the reference-ordered dense QP from the DEVICE linearisation; layout bookkeeping only
+// (IMPCProblem.cpp:150-194; cost order variableSamplingMPC.cpp:70-76, row order :77-84).
+int vsmpc_assemble_dense(vsmpc_handle* h, const double* in_one, double* H, double* g, double* Ac, double* lo,
+                         double* hi) {
+    if (h == nullptr || in_one == nullptr || H == nullptr || g == nullptr || Ac == nullptr || lo == nullptr ||
+        hi == nullptr)
+        return VSMPC_ERR_INVALID_ARG;
+    std::vector<double> A(NX * NX), Bj(NX * NJ), Bt(NX * NTH), c(NX), dt(MAX_STAGES);
+    int rc = vsmpc_linearize_batch(h, in_one, 1, A.data(), Bj.data(), Bt.data(), c.data(), dt.data());
+    if (rc != VSMPC_OK) return rc;
+    const vsmpc_config& cf = h->cfg;
+    const int N = cf.n_iter, nS = cf.n_iter_small, Hc = cf.control_horizon;
+    const int nvar = h->n_var, ncon = h->n_con;
+    const int offJ = NX * (N + 1), offV = offJ + NJ * Hc, nvb = Hc - nS + 1;
+    memset(H, 0, sizeof(double) * size_t(nvar) * nvar);
+    memset(g, 0, sizeof(double) * nvar);
+    memset(Ac, 0, sizeof(double) * size_t(ncon) * nvar);
+    memset(lo, 0, sizeof(double) * ncon);
+    memset(hi, 0, sizeof(double) * ncon);
+    auto Hat = [&](int r, int cc) -> double& { return H[size_t(r) * nvar + cc]; };
+    auto Aat = [&](int r, int cc) -> double& { return Ac[size_t(r) * nvar + cc]; };
+    double q[NX] = {0};
+    for (int i = 0; i < 3; ++i) {
+        q[i] = cf.w_com_pos[i]; q[3 + i] = cf.w_lin_mom[i]; q[6 + i] = cf.w_rpy[i];
+        q[9 + i] = cf.w_ang_mom[i]; q[20 + i] = cf.w_com_pos_err[i]; q[23 + i] = cf.w_rpy_err[i];
+    }
+    // ReferenceTrackingCost (costsVSMPC.cpp:166-178)
+    for (int i = 1; i <= N; ++i) {
+        const int col = (i - 1) < nS ? 0 : (i - 1) - nS;
+        for (int r = 0; r < NX; ++r) {
+            Hat(i * NX + r, i * NX + r) += q[r];
+            if (r < 12) g[i * NX + r] += -q[r] * in_one[VSMPC_IN_XREF + col * 12 + r];
+        }
+    }
+    // RegualarizationCost (costsVSMPC.cpp:375-409)
+    for (int i = 0; i < Hc; ++i)
+        for (int r = 0; r < NJ; ++r) Hat(offJ + i * NJ + r, offJ + i * NJ + r) += cf.w_delta_joint[r];
+    for (int i = 0; i < Hc - nS; ++i)
+        for (int r = 0; r < NTH; ++r) {
+            const int a = offV + i * NTH + r, b = offV + (i + 1) * NTH + r;
+            Hat(a, a) += cf.w_throttle; Hat(b, a) -= cf.w_throttle;
+            Hat(a, b) -= cf.w_throttle; Hat(b, b) += cf.w_throttle;
+        }
+    // ThrottleInitialValueCost (costsVSMPC.cpp:468-487)
+    double vprev[NTH];
+    for (int r = 0; r < NTH; ++r) {
+        vprev[r] = Jet::v_of_throttle(in_one[VSMPC_IN_UPREV + r]);
+        Hat(offV + r, offV + r) += cf.w_initial_throttle;
+        g[offV + r] += -cf.w_initial_throttle * vprev[r];
+    }
+    // JointPositionRegularizationCost (costsVSMPC.cpp:558-592)
+    for (int i = 0; i < Hc; ++i)
+        for (int r = 0; r < NJ; ++r) {
+            Hat(offJ + i * NJ + r, offJ + i * NJ + r) += cf.w_reg_joint_pos;
+            g[offJ + i * NJ + r] += cf.w_reg_joint_pos * in_one[VSMPC_IN_QERR + r];
+        }
+    // ConstraintSystemDynamicVS (constraintsVSMPC.cpp:76-131)
+    for (int i = 0; i < N; ++i) {
+        const double d = dt[i];
+        const int jb = i < Hc ? i : Hc - 1;
+        const int tb = i < nS ? 0 : (i < Hc ? i - (nS - 1) : Hc - nS);
+        for (int r = 0; r < NX; ++r) {
+            for (int cc = 0; cc < NX; ++cc) Aat(i * NX + r, i * NX + cc) = (r == cc ? 1.0 : 0.0) + d * A[r * NX + cc];
+            Aat(i * NX + r, (i + 1) * NX + r) = -1.0;
+            for (int cc = 0; cc < NJ; ++cc) Aat(i * NX + r, offJ + jb * NJ + cc) = d * Bj[r * NJ + cc];
+            for (int cc = 0; cc < NTH; ++cc) Aat(i * NX + r, offV + tb * NTH + cc) = d * Bt[r * NTH + cc];
+            lo[i * NX + r] = -d * c[r];
+            hi[i * NX + r] = -d * c[r];
+        }
+    }
+    // ConstraintInitialState (IQPUtilsMPC.cpp:71-92)
+    const int r0 = N * NX;
+    for (int r = 0; r < NX; ++r) {
+        Aat(r0 + r, r) = 1.0;
+        lo[r0 + r] = hi[r0 + r] = in_one[VSMPC_IN_X0 + r];
+    }
+    // ThrottleConstraint (constraintsVSMPC.cpp:338-365); trailing rows stay 0 in [0,0]
+    const int r1 = r0 + NX;
+    const bool hold = in_one[VSMPC_IN_HOLD] != 0.0;
+    for (int i = 0; i < nvb; ++i)
+        for (int r = 0; r < NTH; ++r) {
+            Aat(r1 + i * NTH + r, offV + i * NTH + r) = 1.0;
+            if (hold && i == 0) {
+                lo[r1 + r] = hi[r1 + r] = vprev[r];
+            } else {
+                lo[r1 + i * NTH + r] = h->dev.vmin;
+                hi[r1 + i * NTH + r] = h->dev.vmax;
+            }
+        }
+    return VSMPC_OK;
+}
+
+int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, double* Lfac) {
+    if (h == nullptr || in_one == nullptr) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t np2 = size_t(h->n_p) * h->n_p;
+    HIP_TRY(hipMemcpy(h->d_in, in_one, h->n_in * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, 1, h->d_x, h->d_fm, h->d_status, h->d_iters, h->d_dbg,
+                         h->d_dbg + np2, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (M) HIP_TRY(hipMemcpy(M, h->d_dbg, np2 * sizeof(double), hipMemcpyDeviceToHost));
+    if (Lfac) HIP_TRY(hipMemcpy(Lfac, h->d_dbg + np2, np2 * sizeof(double), hipMemcpyDeviceToHost));
+    return VSMPC_OK;
+}
+
+int vsmpc_timing_begin(vsmpc_handle* h, void* stream) {
+    if (h == nullptr) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipEventRecord(h->ev0, static_cast<hipStream_t>(stream)));
+    return VSMPC_OK;
+}
+
+int vsmpc_timing_end(vsmpc_handle* h, void* stream, int launches, float* ms_per_launch) {
+    if (h == nullptr || ms_per_launch == nullptr || launches <= 0) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipEventRecord(h->ev1, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_launch = ms / float(launches);
+    return VSMPC_OK;
+}
+
+const char* vsmpc_strerror(int code) {
+    switch (code) {
+        case VSMPC_OK: return "ok";
+        case VSMPC_ERR_INVALID_ARG: return "invalid argument";
+        case VSMPC_ERR_UNSUPPORTED_CONFIG: return "unsupported MPC configuration (no kernel instantiation)";
+        case VSMPC_ERR_BATCH_TOO_LARGE: return "batch exceeds max_batch of the handle";
+        case VSMPC_ERR_HIP: return g_hip_msg[0] ? g_hip_msg : "HIP runtime error";
+        case VSMPC_ERR_ALLOC: return "allocation failed";
+        default: return "unknown error";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// Shared device/host definitions for the batched multi-rate MPC kernels (gfx950 only).
+//
+// Restates, for the device, the pure-scalar parts of the reference path:
+//   JetModel            utils/src/JetModel.cpp:10-114
+//   JetDynamicVS        momentum-based-linear-mpc-lib/src/variableSamplingMPC/systemDynamicsVSMPC.cpp:431-461
+//   move-blocking maps  momentum-based-linear-mpc-lib/src/variableSamplingMPC/constraintsVSMPC.cpp:89-128
+// (paths relative to /root/reference/src/flight-controller/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/vsmpc.h"
+
+#define VS_HD __host__ __device__ __forceinline__
+#define VS_DEV __device__ __forceinline__
+
+namespace vsmpc {
+
+constexpr int NX = VSMPC_N_STATES;   // 26
+constexpr int NJ = VSMPC_N_JOINTS;   // 8
+constexpr int NTH = VSMPC_N_THRUSTS; // 4
+constexpr int NWROWS = 18;           // weighted state rows: 0..11 and 20..25 (costsVSMPC.cpp:78-93)
+constexpr int MAX_STAGES = 40;
+
+// Compile-time problem dimensions (variableSamplingMPC.cpp:42-45).
+template <int N_, int NS_, int HC_>
+struct Dims {
+    static constexpr int N = N_;       // nIter
+    static constexpr int NS = NS_;     // nIterSmall
+    static constexpr int HC = HC_;     // controlHorizon
+    static constexpr int NVB = HC - NS + 1;  // throttle blocks
+    static constexpr int NU = NJ * HC;       // joint increments
+    static constexpr int NV = NTH * NVB;     // warped throttles
+    static constexpr int NZ = NU + NV;       // condensed inputs
+    static constexpr int NP = ((NZ + 1 + 15) / 16) * 16;  // + gradient row, padded to tiles of 16
+    static constexpr int NT = NP / 16;
+    static constexpr int NTRI = NT * (NT + 1) / 2;
+    static constexpr int NREF = N - NS + 1;
+    static constexpr int NIN = VSMPC_IN_XREF + 12 * NREF;
+    static constexpr int NXS = NX * (N + 1);
+    static constexpr int NVAR = NXS + NZ;
+    static constexpr int NCON = NXS + NTH * (N - NS + 1);
+    static constexpr int YS = NP + 16;       // Y row stride (doubles): 16 mod 32 -> conflict-free b64 reads
+    static constexpr int TS = 16 * 17;       // tile stride (16 rows, padded row stride 17)
+    static_assert(N <= MAX_STAGES, "horizon too long");
+    static_assert(NV <= 64, "throttle block must fit one wavefront");
+};
+
+// Kernel-argument block: everything that depends only on the configuration.
+struct DevCfg {
+    double dt[MAX_STAGES];     // per-stage step (constraintsVSMPC.cpp:45-51,78-84)
+    double sq[NWROWS];         // sqrt of the 18 non-zero state weights
+    double wj[NJ];             // weightDeltaJoint + weightRegularizationJointPos (costsVSMPC.cpp:375-381,564-571)
+    double w_reg;              // weightRegularizationJointPos
+    double w_thr;              // weightThrottle
+    double w_init;             // weightInitialThrottle
+    double vmin, vmax;         // constraintsVSMPC.cpp:329-332
+    int use_jet;               // useJetDynamic
+    int max_as_iter;           // active-set iteration cap
+};
+
+// ---------------------------------------------------------------- jet model (JetModel.cpp)
+struct Jet {
+    static constexpr double c0 = -4.64730485e-01, c1 = -8.13171858e+00, c2 = -6.19539230e+00,
+                            c3 = 6.61113140e-01, c4 = 1.67673231e+00, c5 = -4.83287064e-01,
+                            c6 = 8.77996617e+00, c7 = -1.01096376e+00, c8 = -5.86442286e-01,
+                            c9 = 5.19093322e-01, c10 = -4.23782666e-01, c11 = -1.45705257e+00,
+                            c12 = -7.83052261e-03;
+    static constexpr double muT = 108.309, sgT = 65.793, muU = 47.333, sgU = 31.483;
+
+    static VS_HD double f(double T, double Td) { return c0 + c1 * T + c2 * Td + c3 * T * Td + c4 * T * T + c5 * Td * Td; }
+    static VS_HD double g(double T, double Td) { return c6 + c7 * T + c8 * Td + c9 * T * Td + c10 * T * T + c11 * Td * Td; }
+    static VS_HD double df_dT(double T, double Td) { return c1 + c3 * Td + 2 * c4 * T; }
+    static VS_HD double df_dTd(double T, double Td) { return c2 + c3 * T + 2 * c5 * Td; }
+    static VS_HD double dg_dT(double T, double Td) { return c7 + c9 * Td + 2 * c10 * T; }
+    static VS_HD double dg_dTd(double T, double Td) { return c8 + c9 * T + 2 * c11 * Td; }
+    static VS_HD double v(double u) { return u + c12 * u * u; }
+    static VS_HD double stdT(double T) { return (T - muT) / sgT; }
+    static VS_HD double stdTd(double Td) { return Td / sgT; }
+    static VS_HD double stdU(double u) { return (u - muU) / sgU; }
+    static VS_HD double v_of_throttle(double u_percent) { return v(stdU(u_percent)); }
+    // JetModel::destandardizeThrottle_u2T (JetModel.cpp:93-109)
+    static VS_HD double throttle_of_v(double vv) {
+        double u = (-1.0 + sqrt(1.0 + 4.0 * c12 * vv)) / (2.0 * c12);
+        u = u * sgU + muU;
+        return u < 0.0 ? 0.0 : (u > 100.0 ? 100.0 : u);
+    }
+    // JetDynamicVS::computeF/computeG/compute_dh_dT/compute_dh_dTDot (systemDynamicsVSMPC.cpp:431-461)
+    static VS_HD double F(double T, double Td) { return f(stdT(T), stdTd(Td)) * sgT; }
+    static VS_HD double G(double T, double Td) { return g(stdT(T), stdTd(Td)) * sgT; }
+    static VS_HD double dh_dT(double T, double Td, double thr) {
+        const double a = stdT(T), b = stdTd(Td);
+        return df_dT(a, b) + dg_dT(a, b) * v(stdU(thr));
+    }
+    static VS_HD double dh_dTd(double T, double Td, double thr) {
+        const double a = stdT(T), b = stdTd(Td);
+        return df_dTd(a, b) + dg_dTd(a, b) * v(stdU(thr));
+    }
+};
+
+// move blocking (constraintsVSMPC.cpp:89-128)
+template <class D>
+VS_HD int joint_block_of_stage(int k) { return k < D::HC ? k : D::HC - 1; }
+template <class D>
+VS_HD int throttle_block_of_stage(int k) {
+    return k < D::NS ? 0 : (k < D::HC ? k - (D::NS - 1) : D::HC - D::NS);
+}
+
+// Internal condensed column order: [U_0..U_{HC-1} | v_1..v_{NVB-1} | v_0 | gradient | pad].
+// v_0 goes last so that the 20-tick throttle hold (constraintsVSMPC.cpp:351) pins the trailing block.
+template <class D>
+VS_HD int v_block_of_internal(int q) {  // q in [0, NV): internal throttle index -> reference block
+    const int b = q >> 2;
+    return b < D::NVB - 1 ? b + 1 : 0;
+}
+// first stage at which internal column c becomes non-zero in the sensitivity recursion
+template <class D>
+VS_HD int col_first_stage(int c) {
+    if (c < D::NU) return c >> 3;
+    if (c < D::NZ) {
+        const int b = v_block_of_internal<D>(c - D::NU);
+        return b == 0 ? 0 : D::NS + b - 1;
+    }
+    if (c == D::NZ) return 0;
+    return 1 << 20;
+}
+template <class D>
+VS_HD int tile_first_stage(int t) {
+    int s = 1 << 20;
+    for (int c = 16 * t; c < 16 * t + 16; ++c) {
+        const int f = col_first_stage<D>(c);
+        s = f < s ? f : s;
+    }
+    return s;
+}
+
+VS_HD int wrow(int r) { return r < 12 ? r : r + 8; }  // weighted-row index -> state row
+
+}  // namespace vsmpc

@@ -1,0 +1,21 @@
+// Host-visible launch interface of vsmpc_kernels.hip (internal to the library; the public
+// boundary is include/vsmpc.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vsmpc_device.hpp"
+
+namespace vsmpc {
+
+enum Variant { VARIANT_NONE = 0, VARIANT_PAPER = 1 };
+
+int select_variant(int n_iter, int n_iter_small, int control_horizon);
+const char* variant_kernel_name(int variant);
+int variant_condensed_dim(int variant);
+
+hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+                        int* d_status, int* d_iters, double* dbgM, double* dbgL, hipStream_t stream);
+hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
+                            double* Bt, double* c, hipStream_t stream);
+
+}  // namespace vsmpc
