@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched multi-rate MPC solve path (BASELINE.json metric: MPC solves/s).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path (linearise -> condense -> factor -> box QP -> simulate) over one
+batch of synthetic instances that is already resident in HBM.  At N=1 the batch is
+BASELINE.json configs[1] (batch=256 hover initial states, paper horizon/rates); with N ranks every
+rank solves its own 256-instance slice (weak scaling, per-rank seeds, no data-path collective).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
+
+# SURVEY.md 8(d) / BASELINE.md section 3: algorithmic FLOPs and HBM bytes per solve
+F_ALG = {"paper": 3.086e6, "horizon2x": 6.17e6}
+BYTES_ALG = {"paper": 7064, "horizon2x": 12488}
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec; not listed in MI355X_MICROARCH.md)
+
+
+def cpu_baseline(cfg_name: str, inputs: np.ndarray, budget_s: float = 15.0):
+    """Times the oracle on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+    The oracle is test infrastructure: it is the thing timed here, never the thing shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c  # C restatement of the reference algorithm (assembly + OSQP-style ADMM + polish)
+        return oracle_c.time_baseline(cfg_name, inputs, budget_s)
+    except Exception as exc:  # pragma: no cover - the C oracle is built by __graft_entry__.build()
+        note = f"C oracle unavailable ({type(exc).__name__}: {exc}); numpy restatement timed instead"
+    import vsmpc_ref as ref
+    rcfg = ref.paper_config() if cfg_name == "paper" else ref.horizon2x_config()
+    n, t0 = 0, time.perf_counter()
+    while n < len(inputs) and (time.perf_counter() - t0) < budget_s:
+        ref.solve_instance(rcfg, inputs[n])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{n} instances of the benchmark batch, numpy oracle (dense assembly + null-space "
+                      f"active set), {dt:.1f} s; {note}"}
+
+
+def parity_sample(cfg_name: str, inputs: np.ndarray, x: np.ndarray, k: int = 8) -> float:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vsmpc_ref as ref
+    rcfg = ref.paper_config() if cfg_name == "paper" else ref.horizon2x_config()
+    worst = 0.0
+    for b in np.linspace(0, len(inputs) - 1, k).astype(int):
+        xr, _, _, _ = ref.solve_instance(rcfg, inputs[b])
+        worst = max(worst, float(np.abs(x[b] - xr).max() / max(1.0, np.abs(xr).max())))
+    return worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="instances per GPU (configs[1] = 256)")
+    ap.add_argument("--workload", default="hover", choices=["hover", "takeoff", "montecarlo"])
+    ap.add_argument("--config", default="paper", choices=["paper", "horizon2x"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MPC path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    solver = importlib.import_module(PKG + ".solver")
+    sharding = importlib.import_module(PKG + ".sharding")
+    import __graft_entry__ as ge
+    ge.build()
+
+    cfg = pkg.paper_config() if args.config == "paper" else pkg.horizon2x_config()
+    B = args.batch
+    first, count = sharding.shard_range(B * world, rank, world)   # contiguous slice, no exchange
+    inputs = synth.make_batch(cfg, count, workload=args.workload, first_index=first)
+    mpc = solver.BatchedVSMPC(cfg, device=local_rank, max_batch=count)
+
+    d_in = torch.from_numpy(inputs).to(dev)
+    d_x = torch.empty((count, cfg.n_var), dtype=torch.float64, device=dev)
+    d_fm = torch.empty((count, 24), dtype=torch.float64, device=dev)
+    d_st = torch.empty(count, dtype=torch.int32, device=dev)
+    d_it = torch.empty(count, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        mpc.solve_device(d_in, d_x, d_fm, d_st, d_it, stream)
+    torch.cuda.synchronize(dev)
+
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    mpc.timing_begin(stream)                     # HIP events on the launch stream bracket the same K launches
+    for _ in range(args.steps):
+        mpc.solve_device(d_in, d_x, d_fm, d_st, d_it, stream)
+    kernel_ms = mpc.timing_end(stream, args.steps)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    solved = torch.tensor([int((d_st == 1).sum().item())], dtype=torch.int64, device=dev)
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(solved, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_solved = int(solved.item())
+    kernel_ms = float(kms.item())
+
+    if rank == 0:
+        total = B * world
+        value = total * args.steps / elapsed
+        achieved_tflops = F_ALG[args.config] * count / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            rec = json.load(open(tpath)).get(f"{args.config}:{args.workload}:{B}")
+            traffic = rec["bytes_per_launch"] if rec else None
+        out = {
+            "metric": "MPC solves/sec (whole node), iRonCub paper horizon" if args.config == "paper"
+                      else "MPC solves/sec (whole node), 2x horizon",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch={B} {args.workload} initial states per GPU, "
+                                   f"{'paper horizon/rates (nIter=17,nIterSmall=7,controlHorizon=12)' if args.config == 'paper' else '2x horizon (nIter=34,nIterSmall=14,controlHorizon=24)'}",
+                       "instances_total": total, "qp": f"{cfg.n_var} vars / {cfg.n_con} rows",
+                       "parallelism": f"batch split over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": mpc.kernel_name, "kernel_us_per_launch": kernel_ms * 1e3,
+                         "alg_flops_per_solve": F_ALG[args.config], "alg_bytes_per_solve": BYTES_ALG[args.config],
+                         "hbm_frac_informational": BYTES_ALG[args.config] * count / (kernel_ms * 1e-3) / 8.0e12},
+            "solved": total_solved, "instances_per_step": total,
+        }
+        x_host = d_x.cpu().numpy()
+        out["parity_max_rel_err_vs_oracle"] = parity_sample(args.config, inputs, x_host)
+        if not args.no_latency:
+            one = solver.BatchedVSMPC(cfg, device=local_rank, max_batch=1)
+            lat = []
+            for i in range(1020):
+                torch.cuda.synchronize(dev)
+                a = time.perf_counter()
+                one.solve_device(d_in[:1], d_x[:1], d_fm[:1], d_st[:1], d_it[:1], stream)
+                torch.cuda.synchronize(dev)
+                lat.append(time.perf_counter() - a)
+            lat = np.array(lat[20:])
+            out["latency_single_solve_us"] = {"p50": float(np.percentile(lat, 50) * 1e6),
+                                              "p99": float(np.percentile(lat, 99) * 1e6),
+                                              "what": "batch=1, 1000 repeats, host wall-clock incl. launch + sync"}
+            one.close()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, inputs)
+        print(json.dumps(out), flush=True)
+
+    barrier()
+    mpc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

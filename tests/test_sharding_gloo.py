@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the instance range, rebuild their slices from
+per-instance seeds, and agree through the off-data-path collectives (counters, first-move gather)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
+
+
+def test_shard_range_covers_exactly():
+    sys.path.insert(0, ROOT)
+    sh = importlib.import_module(PKG + ".sharding")
+    for total in (0, 1, 7, 256, 32768, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [sh.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    assert sh.shard_range(32768, 3, 8) == (3 * 4096, 4096)       # BASELINE.json configs[3]
+    with pytest.raises(ValueError):
+        sh.shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharding")
+    synth = importlib.import_module(PKG + ".synth")
+    cfg = pkg.paper_config()
+    local = sh.rank_inputs(cfg, synth, total, rank, world, workload="takeoff")
+    first, count = sh.shard_range(total, rank, world)
+    # stand-in "first-move" block derived from the inputs: tests the gather order, not the solver
+    fm = torch.from_numpy(local[:, :24].copy())
+    gathered = sh.gather_first_moves(fm, total)
+    solved, iters, err, el = sh.reduce_counters(count, 2 * count, 1e-9 * (rank + 1), 0.5 + rank)
+    q.put((rank, first, count, local[:, :30].copy(), gathered.numpy(), solved, iters, err, el))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    total, world = 13, 2          # ragged on purpose
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    full = synth.make_batch(pkg.paper_config(), total, workload="takeoff")
+    assert [r[2] for r in res] == [7, 6] and [r[1] for r in res] == [0, 7]
+    np.testing.assert_array_equal(np.concatenate([r[3] for r in res]), full[:, :30])   # slices = global batch
+    for r in res:
+        np.testing.assert_array_equal(r[4], full[:, :24])                               # gather restores global order
+        assert r[5] == total and r[6] == 2 * total and abs(r[7] - 2e-9) < 1e-20 and r[8] == 1.5
