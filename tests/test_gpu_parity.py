@@ -161,7 +161,7 @@ def test_full_batch_properties(mpc, ref, synth, layout, batch, workload):
     np.testing.assert_array_equal(fm[:, 0:8], x[:, 468:476])
     np.testing.assert_array_equal(fm[:, 8:12], x[:, 564:568])
     np.testing.assert_array_equal(fm[:, 16:24], x[:, 26 + 12:26 + 20])
-    np.testing.assert_allclose(fm[:, 12:16], ref.destd_throttle(x[:, 564:568]), rtol=1e-12)
+    np.testing.assert_allclose(fm[:, 12:16], ref.destd_throttle(x[:, 564:568]), rtol=1e-9, atol=1e-9)  # -1+sqrt(1+4cv) cancels ~2 digits
     vmin, vmax = ref.throttle_bounds(rcfg)
     assert x[:, 564:588].min() >= vmin and x[:, 564:588].max() <= vmax
     hold = recs[:, layout.IN_HOLD] != 0
@@ -218,23 +218,22 @@ def test_edge_cases(mpc, solver_mod, synth, layout, ref):
 
 
 def test_saturated_throttles(mpc, ref, synth, layout):
-    """Force most throttle bounds active: thrust far below what hover needs and a distant reference."""
+    """Force many throttle bounds active on a free (non-hold) tick: CoM reference 30 m away."""
     cfg, rcfg = layout.paper_config(), ref.paper_config()
     recs = synth.make_batch(cfg, 8, workload="hover", first_index=40)
-    recs[:, layout.IN_T0:layout.IN_T0 + 4] *= 0.3
-    recs[:, 12:16] *= 0.3
-    recs[:, layout.IN_TDES:layout.IN_TDES + 4] *= 0.3
-    recs[:, layout.IN_XREF + 2::12] += 3.0            # CoM z reference 3 m above
-    recs[4:, layout.IN_XREF + 2::12] -= 6.0           # ... or below
+    recs[:, layout.IN_HOLD] = 0.0
+    recs[:, layout.IN_XREF + 2::12] += 30.0
+    recs[4:, layout.IN_XREF + 2::12] -= 60.0
+    recs[:, 22] = recs[:, 2] - recs[:, layout.IN_XREF + 2]      # keep X0's position error consistent
     x, fm, st, it = mpc.solve(recs)
     assert (st == 1).all()
     vmin, vmax = ref.throttle_bounds(rcfg)
     nact = 0
     for b, rec in enumerate(recs):
         xr, yr, itr, _ = ref.solve_instance(rcfg, rec)
-        assert relerr(x[b], xr) < TOL
+        assert relerr(x[b], xr) < TOL and it[b] == itr
         nact += int((np.abs(xr[564:] - vmax) < 1e-12).sum() + (np.abs(xr[564:] - vmin) < 1e-12).sum())
-    assert nact >= 40                                   # the case really saturates
+    assert nact >= 24 and it.max() >= 4                 # the case really saturates and iterates
 
 
 def test_status_on_non_finite_input(mpc, synth, layout):
