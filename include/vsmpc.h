@@ -154,6 +154,10 @@ int vsmpc_assemble_dense(vsmpc_handle* h, const double* in_one, double* H, doubl
 int vsmpc_condensed_dim(const vsmpc_handle* h);
 int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, double* Lfac);
 
+/* Diagnostic build of the solve kernel (separate instantiation, never the timed one): s_memtime stamps of
+ * workgroup thread 0 at the 10 phase boundaries P0..P6 of every instance, stamps16[batch*16]. */
+int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsigned long long* stamps16);
+
 /* Average device time per launch of the solve kernel over the launches enqueued between
  * vsmpc_timing_begin and vsmpc_timing_end on the handle's stream, measured with HIP events on the
  * stream the kernel is launched on.  Returns milliseconds through *ms_per_launch. */

@@ -166,7 +166,7 @@ int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, dou
     if (h == nullptr || d_in == nullptr || d_status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
     if (batch == 0) return VSMPC_OK;
     HIP_TRY(launch_solve(h->variant, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
-                         static_cast<hipStream_t>(stream)));
+                         nullptr, static_cast<hipStream_t>(stream)));
     return VSMPC_OK;
 }
 
@@ -180,7 +180,7 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
     const size_t B = size_t(batch);
     HIP_TRY(hipMemcpyAsync(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                         nullptr, s));
+                         nullptr, nullptr, s));
     if (x) HIP_TRY(hipMemcpyAsync(x, h->d_x, B * h->n_var * sizeof(double), hipMemcpyDeviceToHost, s));
     if (first_move)
         HIP_TRY(hipMemcpyAsync(first_move, h->d_fm, B * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -310,10 +310,29 @@ int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, doub
     const size_t np2 = size_t(h->n_p) * h->n_p;
     HIP_TRY(hipMemcpy(h->d_in, in_one, h->n_in * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, 1, h->d_x, h->d_fm, h->d_status, h->d_iters, h->d_dbg,
-                         h->d_dbg + np2, nullptr));
+                         h->d_dbg + np2, nullptr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     if (M) HIP_TRY(hipMemcpy(M, h->d_dbg, np2 * sizeof(double), hipMemcpyDeviceToHost));
     if (Lfac) HIP_TRY(hipMemcpy(Lfac, h->d_dbg + np2, np2 * sizeof(double), hipMemcpyDeviceToHost));
+    return VSMPC_OK;
+}
+
+int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsigned long long* stamps16) {
+    if (h == nullptr || in == nullptr || stamps16 == nullptr || batch <= 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned long long* d_st = nullptr;
+    HIP_TRY(hipMalloc(&d_st, size_t(batch) * 16 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d_st, 0, size_t(batch) * 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(h->d_in, in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 3 && e == hipSuccess; ++rep)  // warm instruction caches, keep the last run
+        e = launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+                         nullptr, d_st, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpy(stamps16, d_st, size_t(batch) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d_st);
+    if (e != hipSuccess) return hip_fail(e, "vsmpc_debug_phase_cycles");
     return VSMPC_OK;
 }
 

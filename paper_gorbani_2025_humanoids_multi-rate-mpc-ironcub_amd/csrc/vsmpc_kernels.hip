@@ -4,12 +4,15 @@
 // (IMPCProblem.cpp:150-298, variableSamplingMPC.cpp:88-112) with a structure-exploiting exact solve:
 //
 //   P0 linearise   A, Bj, Bt, c in LDS                       (systemDynamicsVSMPC.cpp:79-103,288-319,384-429)
-//   P1 condense    sensitivity recursion, one condensed column per thread in registers;
+//   P1 condense    sensitivity recursion in registers: thread (half, col) carries the linear-momentum
+//                  half (p, h_lin, e_pos | T, Tdot) or the angular half (rpy, h_ang, e_rpy | T, Tdot) of
+//                  one condensed column; two nodes (36 weighted rows) per pass;
 //                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
 //   P3 cholesky    blocked right-looking LL^T on 16x16 LDS tiles, trailing updates on MFMA
-//   P4 box QP      Schur complement on the warped throttles, block principal pivoting, one wavefront
+//   P4 box QP      free back-substitution first; only if a throttle bound is violated: Schur complement
+//                  on the warped throttles + block principal pivoting in one wavefront
 //                                                            (constraintsVSMPC.cpp:338-365)
 //   P5 back-subst  joints from the factor
 //   P6 simulate    state trajectory, primal in the reference variable order, first-move block
@@ -33,6 +36,21 @@ VS_DEV double readlane_f64(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/sqrt(d) and 1/d: hardware seed + two Newton steps (full double precision to ~2 ulp)
+VS_DEV double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+VS_DEV double fast_rcp(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = y * fma(-d, y, 2.0);
+    y = y * fma(-d, y, 2.0);
+    return y;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS carve-up (doubles)
 // ------------------------------------------------------------------------------------------------
@@ -52,9 +70,14 @@ struct Smem {
     static constexpr int oV = oSvec + D::NV;
     static constexpr int oX = oV + D::NV;
     static constexpr int oFlags = oX + D::NXS;       // 4 doubles worth of int flags
-    static constexpr int oY = (oFlags + 4 + 3) & ~3;
-    static constexpr int oM = oY + 2 * 20 * D::YS;
-    static constexpr int total = oM + D::NTRI * D::TS;
+    static constexpr int oEllV = oFlags + 4;         // P6: sparse rows of A, 8 entries per state row
+    static constexpr int oEllC = oEllV + NX * 8;     // (ints, 8 per row -> NX*4 doubles)
+    static constexpr int oY = (oEllC + NX * 4 + 3) & ~3;
+    static constexpr int YROWS = 36;                 // two nodes x 18 weighted rows = 9 exact MFMA k-steps
+    static constexpr int sizeY = 2 * YROWS * D::YS;  // double-buffered
+    static constexpr int oM = oY;                    // the factor's tiles reuse the Y buffers (dead after P1)
+    static constexpr int sizeM = D::NTRI * D::TS;
+    static constexpr int total = oY + (sizeY > sizeM ? sizeY : sizeM);
     static constexpr size_t bytes = size_t(total) * sizeof(double);
 };
 
@@ -199,11 +222,34 @@ VS_DEV double input_cost_term(const DevCfg& cfg, const double* __restrict__ sIn,
 // ------------------------------------------------------------------------------------------------
 // the solve kernel
 // ------------------------------------------------------------------------------------------------
-template <class D>
+// STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
+// `stamps` (its own buffer, never read by the kernel).  The shipped instantiation has STAMPS = false.
+template <class D, bool STAMPS>
 __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* __restrict__ xout, double* __restrict__ fmout,
                                                          int* __restrict__ status_out, int* __restrict__ iters_out,
-                                                         double* __restrict__ dbgM, double* __restrict__ dbgL) {
+                                                         double* __restrict__ dbgM, double* __restrict__ dbgL,
+                                                         unsigned long long* __restrict__ stamps) {
+#define VS_STAMP(i)                                                                         \
+    do {                                                                                    \
+        if constexpr (STAMPS) {                                                             \
+            if (threadIdx.x == 0) stamps[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                   \
+    } while (0)
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_mark = 0;
+#define VS_TIC()                                                     \
+    do {                                                             \
+        if constexpr (STAMPS) t_mark = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define VS_TOC(i)                                                                    \
+    do {                                                                             \
+        if constexpr (STAMPS) {                                                      \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();           \
+            t_acc[i] += t_now - t_mark;                                              \
+            t_mark = t_now;                                                          \
+        }                                                                            \
+    } while (0)
     using S = Smem<D>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sIn = smem + S::oIn;
@@ -219,7 +265,9 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     double* sSvec = smem + S::oSvec;
     double* sV = smem + S::oV;
     double* sX = smem + S::oX;
-    int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);  // [0]=numerical failure, [1]=status, [2]=iters
+    int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);  // [0]=numerical failure, [1]=status, [2]=iters, [3]=bound violated
+    double* sEllV = smem + S::oEllV;
+    int* sEllC = reinterpret_cast<int*>(smem + S::oEllC);
     double* sY = smem + S::oY;
     double* sM = smem + S::oM;
 
@@ -229,18 +277,19 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     const int inst = blockIdx.x;
     if (inst >= batch) return;
 
+    VS_STAMP(0);
     // ---------------------------------------------------------------- P0
     for (int i = tid; i < D::NIN; i += BLOCK) sIn[i] = in[size_t(inst) * D::NIN + i];
-    for (int i = tid; i < 2 * 20 * D::YS; i += BLOCK) sY[i] = 0.0;  // rows 18,19 and pad columns stay zero
     if (tid < 4) sFlags[tid] = 0;
     __syncthreads();
     p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, BLOCK);
 
+    VS_STAMP(1);
     // ---------------------------------------------------------------- P1 condense
-    // tiles of the lower triangle are dealt round-robin to the four wavefronts
+    // tiles of the lower triangle are dealt round-robin to the four wavefronts: tile t -> wave t%4, slot t/4
     constexpr int TPW = (D::NTRI + NWAVES - 1) / NWAVES;
     d4 acc[TPW];
-    int ti[TPW], tj[TPW], tstart[TPW];
+    int offA[TPW], offB[TPW], tstart[TPW], ti[TPW], tj[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         acc[q] = d4{0.0, 0.0, 0.0, 0.0};
@@ -256,111 +305,161 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
             ti[q] = tj[q] = 0;
             tstart[q] = 1 << 20;
         }
+        offA[q] = 16 * ti[q];
+        offB[q] = 16 * tj[q];
     }
 
-    // per-column state of the sensitivity recursion (threads 0..NP-1 own one condensed column each)
-    const int col = tid;
-    int kind = 3, blk = 0, comp = 0;  // 0 = joint column, 1 = throttle column, 2 = affine column, 3 = pad
-    if (col < D::NU) { kind = 0; blk = col >> 3; comp = col & 7; }
-    else if (col < D::NZ) { kind = 1; blk = v_block_of_internal<D>(col - D::NU); comp = (col - D::NU) & 3; }
-    else if (col == D::NZ) { kind = 2; }
+    {
+        // thread (half, col): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy);
+        // both carry the jet states (T, Tdot) of their column.  Same code, different coefficient rows.
+        const int half = tid >> 7;
+        const int col = tid & 127;
+        const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
+        const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
+        int kind = 3, blk = 0, comp = 0;  // 0 joint column, 1 throttle column, 2 affine column, 3 pad
+        if (col < D::NU) { kind = 0; blk = col >> 3; comp = col & 7; }
+        else if (col < D::NZ) { kind = 1; blk = v_block_of_internal<D>(col - D::NU); comp = (col - D::NU) & 3; }
+        else if (col == D::NZ) { kind = 2; }
 
-    double s[NX];
-    double bl[3], ba[3], bT[4], bTd[4];
+        double M1[9], Sk[9], Am[12], jon[4], ja[4], jb[4];
 #pragma unroll
-    for (int r = 0; r < NX; ++r) s[r] = (kind == 2) ? sIn[VSMPC_IN_X0 + r] : 0.0;
+        for (int r = 0; r < 3; ++r) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        bl[r] = kind == 0 ? sBj[(3 + r) * NJ + comp] : (kind == 2 ? sC[3 + r] : 0.0);
-        ba[r] = kind == 0 ? sBj[(9 + r) * NJ + comp] : (kind == 2 ? sC[9 + r] : 0.0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bT[i] = kind == 1 ? (i == comp ? sBt[(12 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[12 + i] : 0.0);
-        bTd[i] = kind == 1 ? (i == comp ? sBt[(16 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[16 + i] : 0.0);
-    }
-
-    for (int k = 0; k < D::N; ++k) {
-        double* Yb = sY + (k & 1) * 20 * D::YS;
-        if (tid < D::NP) {
-            const double dt = cfg.dt[k];
-            const bool actJ = (kind == 0 && joint_block_of_stage<D>(k) == blk) || kind == 2;
-            const bool actT = (kind == 1 && throttle_block_of_stage<D>(k) == blk) || kind == 2;
-            double ds[NX];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                double a0 = 0.0, a1 = actJ ? bl[r] : 0.0, a2 = 0.0, a3 = actJ ? ba[r] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    a0 += sA[r * NX + 3 + j] * s[3 + j];
-                    a1 += sA[(3 + r) * NX + 3 + j] * s[3 + j];
-                    a2 += sA[(6 + r) * NX + 9 + j] * s[9 + j];
-                    a3 += sA[(9 + r) * NX + 9 + j] * s[9 + j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a1 += sA[(3 + r) * NX + 12 + j] * s[12 + j];
-                    a3 += sA[(9 + r) * NX + 12 + j] * s[12 + j];
-                }
-                ds[r] = a0;
-                ds[3 + r] = a1;
-                ds[6 + r] = a2;
-                ds[9 + r] = a3;
-                ds[20 + r] = s[r] + (kind == 2 ? sC[20 + r] : 0.0);
-                ds[23 + r] = s[6 + r] + (kind == 2 ? sC[23 + r] : 0.0);
+            for (int c = 0; c < 3; ++c) {
+                M1[3 * r + c] = sA[(xr0 + r) * NX + hr0 + c];
+                Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ds[12 + i] = sA[(12 + i) * NX + 16 + i] * s[16 + i] + (actT ? bT[i] : 0.0);
-                ds[16 + i] = sA[(16 + i) * NX + 12 + i] * s[12 + i] + sA[(16 + i) * NX + 16 + i] * s[16 + i]
-                             + (actT ? bTd[i] : 0.0);
-            }
-#pragma unroll
-            for (int r = 0; r < NX; ++r) s[r] += dt * ds[r];
-            // Y_k = sqrt(Q) (S_k - xref_k on the affine column); reference column map costsVSMPC.cpp:191-200
-            const int rc = k < D::NS ? 0 : k - D::NS;
-#pragma unroll
-            for (int r = 0; r < NWROWS; ++r) {
-                double v = s[wrow(r)];
-                if (kind == 2 && r < 12) v -= sIn[VSMPC_IN_XREF + rc * 12 + r];
-                Yb[r * D::YS + col] = cfg.sq[r] * v;
-            }
+            for (int c = 0; c < 4; ++c) Am[4 * r + c] = sA[(hr0 + r) * NX + 12 + c];
         }
-        __syncthreads();
-        // C += Y_k^T Y_k : D = A*B with A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n]
 #pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-            const double* yrow = Yb + (4 * ks + (lane >> 4)) * D::YS + (lane & 15);
+        for (int i = 0; i < 4; ++i) {
+            jon[i] = sA[(12 + i) * NX + 16 + i];
+            ja[i] = sA[(16 + i) * NX + 12 + i];
+            jb[i] = sA[(16 + i) * NX + 16 + i];
+        }
+        double xs[3], hs[3], es[3], Ts[4], Tds[4];
+        double bh[3], ce[3], bT[4], bTd[4];
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                if (k >= tstart[q]) {
-                    const double a = yrow[16 * ti[q]];
-                    const double b = yrow[16 * tj[q]];
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+        for (int r = 0; r < 3; ++r) {
+            xs[r] = kind == 2 ? sIn[VSMPC_IN_X0 + xr0 + r] : 0.0;
+            hs[r] = kind == 2 ? sIn[VSMPC_IN_X0 + hr0 + r] : 0.0;
+            es[r] = kind == 2 ? sIn[VSMPC_IN_X0 + er0 + r] : 0.0;
+            bh[r] = kind == 0 ? sBj[(hr0 + r) * NJ + comp] : (kind == 2 ? sC[hr0 + r] : 0.0);
+            ce[r] = kind == 2 ? sC[er0 + r] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Ts[i] = kind == 2 ? sIn[VSMPC_IN_X0 + 12 + i] : 0.0;
+            Tds[i] = kind == 2 ? sIn[VSMPC_IN_X0 + 16 + i] : 0.0;
+            bT[i] = kind == 1 ? (i == comp ? sBt[(12 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[12 + i] : 0.0);
+            bTd[i] = kind == 1 ? (i == comp ? sBt[(16 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[16 + i] : 0.0);
+        }
+        double sqx[3], sqh[3], sqe[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { sqx[r] = cfg.sq[yx0 + r]; sqh[r] = cfg.sq[yh0 + r]; sqe[r] = cfg.sq[ye0 + r]; }
+
+        constexpr int NPASS = (D::N + 1) / 2;
+        for (int m = 0; m < NPASS; ++m) {
+            double* Yb = sY + (m & 1) * S::YROWS * D::YS;
+            const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
+            VS_TIC();
+            for (int par = 0; par < nnodes; ++par) {
+                const int k = 2 * m + par;  // stage k -> node k+1
+                const double dt = cfg.dt[k];
+                const bool actJ = (kind == 0 && joint_block_of_stage<D>(k) == blk) || kind == 2;
+                const bool actT = (kind == 1 && throttle_block_of_stage<D>(k) == blk) || kind == 2;
+                double dx[3], dh[3], de[3], dT[4], dTd[4];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double a0 = 0.0, a1 = actJ ? bh[r] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        a0 += M1[3 * r + c] * hs[c];
+                        a1 += Sk[3 * r + c] * hs[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a1 += Am[4 * r + c] * Ts[c];
+                    dx[r] = a0;
+                    dh[r] = a1;
+                    de[r] = xs[r] + ce[r];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dT[i] = jon[i] * Tds[i] + (actT ? bT[i] : 0.0);
+                    dTd[i] = ja[i] * Ts[i] + jb[i] * Tds[i] + (actT ? bTd[i] : 0.0);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { xs[r] += dt * dx[r]; hs[r] += dt * dh[r]; es[r] += dt * de[r]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { Ts[i] += dt * dT[i]; Tds[i] += dt * dTd[i]; }
+                // Y rows of this node: sqrt(Q) (S_k - xref_k on the affine column); column map costsVSMPC.cpp:191-200
+                const int rc = k < D::NS ? 0 : k - D::NS;
+                double* Yn = Yb + 18 * par * D::YS + col;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double vx = xs[r], vh = hs[r];
+                    if (kind == 2) {
+                        vx -= sIn[VSMPC_IN_XREF + rc * 12 + yx0 + r];
+                        vh -= sIn[VSMPC_IN_XREF + rc * 12 + yh0 + r];
+                    }
+                    Yn[(yx0 + r) * D::YS] = sqx[r] * vx;
+                    Yn[(yh0 + r) * D::YS] = sqh[r] * vh;
+                    Yn[(ye0 + r) * D::YS] = sqe[r] * es[r];
                 }
             }
+            if (nnodes == 1)  // rows 18,19 of the last, single-node pass (k-step 4 reads rows 16..19)
+                for (int i = tid; i < 2 * D::YS; i += BLOCK) Yb[18 * D::YS + i] = 0.0;
+            VS_TOC(0);
+            __syncthreads();
+            VS_TOC(1);
+            // C += Y^T Y over this pass: D = A*B, A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n].
+            // Columns that are not active yet are exactly zero, so skipping a tile is only an optimisation.
+            const int last_stage = 2 * m + nnodes - 1;
+            const int nks = nnodes == 2 ? 9 : 5;
+            bool act[TPW];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) act[q] = last_stage >= tstart[q];
+            for (int ks = 0; ks < nks; ++ks) {
+                const double* yrow = Yb + (4 * ks + (lane >> 4)) * D::YS + (lane & 15);
+                double av[TPW], bv[TPW];
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    av[q] = yrow[offA[q]];
+                    bv[q] = yrow[offB[q]];
+                }
+#pragma unroll
+                for (int q = 0; q < TPW; ++q)
+                    if (act[q]) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[q], 0, 0, 0);
+            }
+            VS_TOC(2);
+            // one barrier per pass: the next pass writes the other Y buffer
         }
-        // one barrier per node is enough: the next node writes the other Y buffer
     }
     __syncthreads();
+    VS_STAMP(2);
 
     // ---------------------------------------------------------------- P2 augment: M = C + R, gradient row
+    // (the tile storage reuses the Y buffers: every wave is past its last Y read at the barrier above)
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int t = q * NWAVES + wave;
-        if (t < D::NTRI) {
+        if (q * NWAVES + wave < D::NTRI) {
             double* T = sM + tile_off<D>(ti[q], tj[q]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = (lane >> 4) + 4 * r, c = lane & 15;
-                const int gr = 16 * ti[q] + row, gc = 16 * tj[q] + c;
-                double v = acc[q][r];
-                // the gradient row also picks up the transposed element for the straddling diagonal tile
-                v += input_cost_term<D>(cfg, sIn, sVprev, gr, gc);
-                T[row * 17 + c] = v;
-            }
+            for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * 17 + (lane & 15)] = acc[q][r];
         }
     }
+    __syncthreads();
+    if (tid < D::NU) sM[lower_at<D>(tid, tid)] += cfg.wj[tid & 7];
+    for (int e = tid; e < D::NV * D::NV; e += BLOCK) {
+        const int r = e / D::NV, c = e % D::NV;
+        if (c <= r) {
+            const double v = input_cost_term<D>(cfg, sIn, sVprev, D::NU + r, D::NU + c);
+            if (v != 0.0) sM[lower_at<D>(D::NU + r, D::NU + c)] += v;
+        }
+    }
+    __syncthreads();
+    if (tid < D::NZ) sM[lower_at<D>(D::NZ, tid)] += input_cost_term<D>(cfg, sIn, sVprev, D::NZ, tid);
     __syncthreads();
     if (dbgM != nullptr) {
         for (int e = tid; e < D::NP * D::NP; e += BLOCK) {
@@ -370,10 +469,12 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         __syncthreads();
     }
 
+    VS_STAMP(3);
     // ---------------------------------------------------------------- P3 blocked Cholesky (first NZ pivots)
     for (int p = 0; p < D::NT; ++p) {
         const int npiv = (D::NZ - 16 * p) < 16 ? (D::NZ - 16 * p) : 16;
         double* Tpp = sM + tile_off<D>(p, p);
+        VS_TIC();
         if (wave == 0) {
             // lane r (mod 16) owns row r of the diagonal tile; pivots broadcast with v_readlane
             const int r = lane & 15;
@@ -386,7 +487,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
                 if (j < npiv) {
                     const double d = readlane_f64(a[j], j);
                     bad |= !(d > 0.0);
-                    const double inv = rsqrt(d);
+                    const double inv = fast_rsqrt(d);
                     const double lj = a[j] * inv;
                     a[j] = lj;
                     if (lane == 0) sInvD[16 * p + j] = inv;
@@ -404,6 +505,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
             if (bad && lane == 0) sFlags[0] = 1;
         }
         __syncthreads();
+        VS_TOC(3);
         if (p + 1 < D::NT) {
             // panel solve: one thread per row below the diagonal tile, X L_pp^T = A
             const int nrows = 16 * (D::NT - 1 - p);
@@ -421,9 +523,10 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
                 for (int j = 0; j < 16; ++j) T[j] = x[j];
             }
             __syncthreads();
+            VS_TOC(4);
             // trailing update M_ij -= L_ip L_jp^T, p < j <= i, on the matrix cores
-            const int m = D::NT - 1 - p;
-            const int npairs = m * (m + 1) / 2;
+            const int mm = D::NT - 1 - p;
+            const int npairs = mm * (mm + 1) / 2;
             for (int q = wave; q < npairs; q += NWAVES) {
                 int ii = 0;
                 while ((ii + 1) * (ii + 2) / 2 <= q) ++ii;
@@ -442,6 +545,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
                 for (int r = 0; r < 4; ++r) Tij[((lane >> 4) + 4 * r) * 17 + (lane & 15)] = c4[r];
             }
             __syncthreads();
+            VS_TOC(5);
         }
     }
     if (dbgL != nullptr) {
@@ -452,123 +556,42 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         __syncthreads();
     }
 
-    // ---------------------------------------------------------------- P4 box QP on the throttles
-    // Schur complement S = L22 L22^T, s = L22 (L^-1 g)_v   (row NZ of the factor holds L^-1 g)
-    for (int e = tid; e < D::NV * D::NV; e += BLOCK) {
-        const int r = e / D::NV, c = e % D::NV;
-        const int kmax = r < c ? r : c;
-        double sum = 0.0;
-        for (int k = 0; k <= kmax; ++k)
-            sum += sM[lower_at<D>(D::NU + r, D::NU + k)] * sM[lower_at<D>(D::NU + c, D::NU + k)];
-        sSv[r * (D::NV + 1) + c] = sum;
-    }
-    if (tid < D::NV) {
-        double sum = 0.0;
-        for (int k = 0; k <= tid; ++k) sum += sM[lower_at<D>(D::NU + tid, D::NU + k)] * sM[lower_at<D>(D::NZ, D::NU + k)];
-        sSvec[tid] = sum;
-    }
-    if (tid < D::NP) sW[tid] = tid < D::NZ ? -sM[lower_at<D>(D::NZ, tid)] : 0.0;  // y = -L^-1 g
-    __syncthreads();
-
-    if (wave == 0) {
-        const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
-        const bool valid = lane < D::NV;
-        double row[D::NV];
-#pragma unroll
-        for (int c = 0; c < D::NV; ++c) row[c] = sSv[r * (D::NV + 1) + c];
-        const double svr = sSvec[r];
-        const bool hold = sIn[VSMPC_IN_HOLD] != 0.0;
-        const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
-        const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
-        const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
-        int state = fixed ? -1 : 0;  // 0 free, -1 at lower, +1 at upper
-        double v = 0.0;
-        double gmax = fabs(svr);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
-        const double gtol = 1e-10 * (1.0 + gmax);
-        int best = D::NV + 1, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 0;
-        for (int it = 0; it < cfg.max_as_iter; ++it) {
-            iters = it + 1;
-            const bool isF = valid && state == 0;
-            const unsigned long long Fmask = __ballot(isF);
-            const double vb = isF ? 0.0 : (state < 0 ? lo : hi);
-            double a[D::NV];
-            double b = isF ? -svr : vb;
-#pragma unroll
-            for (int c = 0; c < D::NV; ++c) {
-                const bool cF = (Fmask >> c) & 1ull;
-                const double vbc = readlane_f64(vb, c);
-                if (isF && !cF) b -= row[c] * vbc;
-                a[c] = (isF && cF) ? row[c] : ((c == r && !isF) ? 1.0 : 0.0);
-            }
-            // Gaussian elimination without pivoting (SPD), pivot rows broadcast with v_readlane
-            int bad = 0;
-#pragma unroll
-            for (int j = 0; j < D::NV; ++j) {
-                const double piv = readlane_f64(a[j], j);
-                bad |= !(piv > 0.0);
-                const double f = (lane > j) ? a[j] / piv : 0.0;
-                const double bj = readlane_f64(b, j);
-                b -= f * bj;
-#pragma unroll
-                for (int c = j + 1; c < D::NV; ++c) {
-                    const double pc = readlane_f64(a[c], j);
-                    a[c] -= f * pc;
-                }
-            }
-#pragma unroll
-            for (int j = D::NV - 1; j >= 0; --j) {
-                const double xj = readlane_f64(b, j) / readlane_f64(a[j], j);
-                if (lane == j) v = xj;
-                if (lane < j) b -= a[j] * xj;
-            }
-            if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
-            double grad = svr;
-#pragma unroll
-            for (int c = 0; c < D::NV; ++c) grad += row[c] * readlane_f64(v, c);
-            const double tolv = 1e-12 * (1.0 + fabs(v));
-            const bool vlo = isF && (v < lo - tolv);
-            const bool vhi = isF && (v > hi + tolv);
-            const bool rlo = valid && state == -1 && !fixed && grad < -gtol;
-            const bool rhi = valid && state == 1 && !fixed && grad > gtol;
-            const bool inf = vlo || vhi || rlo || rhi;
-            const unsigned long long imask = __ballot(inf);
-            const int ninf = __popcll(imask);
-            if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
-            bool pick = inf;
-            if (ninf < best) { best = ninf; patience = 3; }
-            else if (patience > 0) { --patience; }
-            else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
-            if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
-        }
-        if (valid) {
-            v = state < 0 ? lo : (state > 0 ? hi : v);  // bound variables sit exactly on their bound
-            sV[lane] = v;
-            sZ[D::NU + lane] = v;
-        }
-        if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+    VS_STAMP(4);
+    // ---------------------------------------------------------------- P4/P5 back-substitution L^T z = y
+    // Row NZ of the factor holds L^-1 g, so y = -row.  The throttles sit at the end of the order, hence the
+    // first tiles of the backward sweep yield the throttles of the QP with only the hold pin enforced.  If
+    // they respect their box the sweep simply continues into the joints (active-set iteration 1 of the
+    // oracle's rule); otherwise the box QP on the Schur complement runs and the sweep restarts with the
+    // throttles prescribed.
+    const bool hold = sIn[VSMPC_IN_HOLD] != 0.0;
+    constexpr int PV = D::NU >> 4;  // first tile that contains a throttle row
+    if (tid < D::NP) {
+        sW[tid] = tid < D::NZ ? -sM[lower_at<D>(D::NZ, tid)] : 0.0;
+        sZ[tid] = 0.0;
     }
     __syncthreads();
+    if (tid < 4 && hold) sZ[D::NZ - 4 + tid] = sVprev[tid];
+    __syncthreads();
 
-    // ---------------------------------------------------------------- P5 back-substitution L^T z = y, v prescribed
-    for (int p = D::NT - 1; p >= 0; --p) {
+    // one tile step of the sweep; `prescribed` = throttles already fixed in sZ
+    auto sweep_tile = [&](int p, bool prescribed) {
         if (wave == 0) {
-            // lane j (mod 16) owns column j of L_pp
-            const int j = lane & 15;
+            const int j = lane & 15;  // lane j owns column j of L_pp
             const double* Tpp = sM + tile_off<D>(p, p);
             double colv[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) colv[k] = (k >= j) ? Tpp[k * 17 + j] : 0.0;
             double w = sW[16 * p + j];
+            const double myinv = sInvD[16 * p + j];
+            const double zfix = sZ[16 * p + j];
             double z = 0.0;
 #pragma unroll
             for (int k = 15; k >= 0; --k) {
-                const int gk = 16 * p + k;  // uniform
+                const int gk = 16 * p + k;  // wave-uniform
                 double zk;
                 if (gk >= D::NZ) zk = 0.0;
-                else if (gk >= D::NU) zk = sZ[gk];
-                else zk = readlane_f64(w, k) * sInvD[gk];
+                else if (gk >= D::NU && (prescribed || (hold && gk >= D::NZ - 4))) zk = readlane_f64(zfix, k);
+                else zk = readlane_f64(w * myinv, k);
                 if (j == k) z = zk;
                 if (j < k) w -= colv[k] * zk;
             }
@@ -578,21 +601,153 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         if (p > 0) {
             if (tid < 16 * p) {
                 const double* T = sM + tile_off<D>(p, tid >> 4) + (tid & 15);
-                double acc2 = 0.0;
+                double a2 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc2 += T[k * 17] * sZ[16 * p + k];
-                sW[tid] -= acc2;
+                for (int k = 0; k < 16; ++k) a2 += T[k * 17] * sZ[16 * p + k];
+                sW[tid] -= a2;
             }
             __syncthreads();
         }
-    }
+    };
 
+    for (int p = D::NT - 1; p >= PV; --p) sweep_tile(p, false);
+    if (wave == 0) {
+        const bool valid = lane < D::NV;
+        const double v = sZ[D::NU + (valid ? lane : 0)];
+        const bool fixed = hold && lane >= D::NV - 4;
+        const double tolv = 1e-12 * (1.0 + fabs(v));
+        const bool viol = valid && !fixed && (v < cfg.vmin - tolv || v > cfg.vmax + tolv);
+        const unsigned long long vm = __ballot(viol);
+        if (lane == 0) { sFlags[3] = vm != 0ull; sFlags[1] = VSMPC_STATUS_SOLVED; sFlags[2] = 1; }
+    }
+    __syncthreads();
+    const bool need_qp = sFlags[3] != 0;
+    VS_STAMP(5);
+
+    if (need_qp) {
+        // Schur complement S = L22 L22^T, s = L22 (L^-1 g)_v
+        for (int e = tid; e < D::NV * D::NV; e += BLOCK) {
+            const int r = e / D::NV, c = e % D::NV;
+            const int kmax = r < c ? r : c;
+            double sum = 0.0;
+            for (int k = 0; k <= kmax; ++k)
+                sum += sM[lower_at<D>(D::NU + r, D::NU + k)] * sM[lower_at<D>(D::NU + c, D::NU + k)];
+            sSv[r * (D::NV + 1) + c] = sum;
+        }
+        if (tid < D::NV) {
+            double sum = 0.0;
+            for (int k = 0; k <= tid; ++k)
+                sum += sM[lower_at<D>(D::NU + tid, D::NU + k)] * sM[lower_at<D>(D::NZ, D::NU + k)];
+            sSvec[tid] = sum;
+        }
+        if (tid < D::NP) sW[tid] = tid < D::NZ ? -sM[lower_at<D>(D::NZ, tid)] : 0.0;  // restart the sweep
+        __syncthreads();
+
+        if (wave == 0) {
+            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
+            const bool valid = lane < D::NV;
+            double row[D::NV];
+#pragma unroll
+            for (int c = 0; c < D::NV; ++c) row[c] = sSv[r * (D::NV + 1) + c];
+            const double svr = sSvec[r];
+            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
+            const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
+            const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
+            int state = fixed ? -1 : 0;  // 0 free, -1 at lower, +1 at upper
+            double v = 0.0;
+            double gmax = fabs(svr);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+            const double gtol = 1e-10 * (1.0 + gmax);
+            int best = D::NV + 1, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 0;
+            for (int it = 0; it < cfg.max_as_iter; ++it) {
+                iters = it + 1;
+                const bool isF = valid && state == 0;
+                const unsigned long long Fmask = __ballot(isF);
+                const double vb = isF ? 0.0 : (state < 0 ? lo : hi);
+                double a[D::NV];
+                double b = isF ? -svr : vb;
+#pragma unroll
+                for (int c = 0; c < D::NV; ++c) {
+                    const bool cF = (Fmask >> c) & 1ull;
+                    const double vbc = readlane_f64(vb, c);
+                    if (isF && !cF) b -= row[c] * vbc;
+                    a[c] = (isF && cF) ? row[c] : ((c == r && !isF) ? 1.0 : 0.0);
+                }
+                // Gaussian elimination without pivoting (SPD), pivot rows broadcast with v_readlane
+                int bad = 0;
+#pragma unroll
+                for (int j = 0; j < D::NV; ++j) {
+                    const double piv = readlane_f64(a[j], j);
+                    bad |= !(piv > 0.0);
+                    const double f = (lane > j) ? a[j] * fast_rcp(piv) : 0.0;
+                    const double bj = readlane_f64(b, j);
+                    b -= f * bj;
+#pragma unroll
+                    for (int c = j + 1; c < D::NV; ++c) {
+                        const double pc = readlane_f64(a[c], j);
+                        a[c] -= f * pc;
+                    }
+                }
+#pragma unroll
+                for (int j = D::NV - 1; j >= 0; --j) {
+                    const double xj = readlane_f64(b, j) * fast_rcp(readlane_f64(a[j], j));
+                    if (lane == j) v = xj;
+                    if (lane < j) b -= a[j] * xj;
+                }
+                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
+                double grad = svr;
+#pragma unroll
+                for (int c = 0; c < D::NV; ++c) grad += row[c] * readlane_f64(v, c);
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool vlo = isF && (v < lo - tolv);
+                const bool vhi = isF && (v > hi + tolv);
+                const bool rlo = valid && state == -1 && !fixed && grad < -gtol;
+                const bool rhi = valid && state == 1 && !fixed && grad > gtol;
+                const bool inf = vlo || vhi || rlo || rhi;
+                const unsigned long long imask = __ballot(inf);
+                const int ninf = __popcll(imask);
+                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
+                bool pick = inf;
+                if (ninf < best) { best = ninf; patience = 3; }
+                else if (patience > 0) { --patience; }
+                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
+                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
+            }
+            if (valid) {
+                v = state < 0 ? lo : (state > 0 ? hi : v);  // bound variables sit exactly on their bound
+                sZ[D::NU + lane] = v;
+            }
+            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+        }
+        __syncthreads();
+        VS_STAMP(6);
+        for (int p = D::NT - 1; p >= 0; --p) sweep_tile(p, true);
+    } else {
+        VS_STAMP(6);
+        for (int p = PV - 1; p >= 0; --p) sweep_tile(p, false);
+    }
+    if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
+    __syncthreads();
+
+    VS_STAMP(7);
     // ---------------------------------------------------------------- P6 forward simulation + outputs
     if (wave == 0) {
         const int r = lane < NX ? lane : NX - 1;
-        double arow[NX], bjrow[NJ], btrow[NTH];
+        // sparse image of row r of A (at most 7 structural non-zeros per row), 8 slots
+        {
+            int n = 0;
+            for (int c = 0; c < NX; ++c) {
+                const double v = sA[r * NX + c];
+                if (v != 0.0 && n < 8 && lane < NX) { sEllV[r * 8 + n] = v; sEllC[r * 8 + n] = c; ++n; }
+            }
+            for (; n < 8; ++n)
+                if (lane < NX) { sEllV[r * 8 + n] = 0.0; sEllC[r * 8 + n] = 0; }
+        }
+        double ev[8], bjrow[NJ], btrow[NTH];
+        int ec[8];
 #pragma unroll
-        for (int c = 0; c < NX; ++c) arow[c] = sA[r * NX + c];
+        for (int e = 0; e < 8; ++e) { ev[e] = sEllV[r * 8 + e]; ec[e] = sEllC[r * 8 + e]; }
 #pragma unroll
         for (int c = 0; c < NJ; ++c) bjrow[c] = sBj[r * NJ + c];
 #pragma unroll
@@ -604,9 +759,10 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
             const int jb = joint_block_of_stage<D>(k);
             const int tb = throttle_block_of_stage<D>(k);
             const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
+            const double* xk = sX + NX * k;  // written by this wavefront in the previous iteration (in-order LDS)
             double d = cr;
 #pragma unroll
-            for (int c = 0; c < NX; ++c) d += arow[c] * readlane_f64(x, c);
+            for (int e = 0; e < 8; ++e) d += ev[e] * xk[ec[e]];
 #pragma unroll
             for (int c = 0; c < NJ; ++c) d += bjrow[c] * sZ[NJ * jb + c];
 #pragma unroll
@@ -616,6 +772,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         }
     }
     __syncthreads();
+    VS_STAMP(8);
 
     if (xout != nullptr) {
         double* xo = xout + size_t(inst) * D::NVAR;
@@ -642,23 +799,32 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         status_out[inst] = st;
         if (iters_out != nullptr) iters_out[inst] = sFlags[2];
     }
+    VS_STAMP(9);
+    if constexpr (STAMPS) {
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 6; ++i) stamps[size_t(blockIdx.x) * 16 + 10 + i] = t_acc[i];
+    }
+#undef VS_STAMP
+#undef VS_TIC
+#undef VS_TOC
 }
 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-template <class D>
+template <class D, bool STAMPS>
 static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
-                                 int* d_status, int* d_iters, double* dbgM, double* dbgL, hipStream_t stream) {
+                                 int* d_status, int* d_iters, double* dbgM, double* dbgL,
+                                 unsigned long long* stamps, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(Smem<D>::bytes));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(solve_kernel<D>, dim3(batch), dim3(BLOCK), Smem<D>::bytes, stream, cfg, d_in, batch, d_x,
-                       d_fm, d_status, d_iters, dbgM, dbgL);
+    hipLaunchKernelGGL((solve_kernel<D, STAMPS>), dim3(batch), dim3(BLOCK), Smem<D>::bytes, stream, cfg, d_in, batch,
+                       d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
     return hipGetLastError();
 }
 
@@ -691,10 +857,15 @@ int variant_condensed_dim(int variant) {
 }
 
 hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
-                        int* d_status, int* d_iters, double* dbgM, double* dbgL, hipStream_t stream) {
+                        int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
+                        hipStream_t stream) {
     switch (variant) {
         case VARIANT_PAPER:
-            return launch_solve_t<DimsPaper>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stream);
+            if (stamps != nullptr)
+                return launch_solve_t<DimsPaper, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
+                                                       stamps, stream);
+            return launch_solve_t<DimsPaper, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
+                                                    nullptr, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -14,7 +14,8 @@ const char* variant_kernel_name(int variant);
 int variant_condensed_dim(int variant);
 
 hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
-                        int* d_status, int* d_iters, double* dbgM, double* dbgL, hipStream_t stream);
+                        int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
+                        hipStream_t stream);
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                             double* Bt, double* c, hipStream_t stream);
 

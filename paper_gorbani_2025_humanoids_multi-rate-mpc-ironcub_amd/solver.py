@@ -126,6 +126,15 @@ class BatchedVSMPC:
         return M, Lf
 
 
+    def phase_cycles(self, inputs: np.ndarray) -> np.ndarray:
+        """Diagnostic build only: per-instance s_memtime stamps at the phase boundaries, [batch, 16]."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.float64)
+        st = np.zeros((inputs.shape[0], 16), dtype=np.uint64)
+        _lib.check(self.lib.vsmpc_debug_phase_cycles(self._h, _ptr(inputs), inputs.shape[0], _ptr(st)),
+                   "vsmpc_debug_phase_cycles")
+        return st
+
+
 class VariableSamplingMPC:
     """Single-instance wrapper with the reference's method names (MPCPyBindings.cpp:22-90).
 

@@ -1,0 +1,26 @@
+"""GPU box: per-phase cycle shares of the solve kernel from the STAMPS diagnostic instantiation."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
+import __graft_entry__ as ge
+ge.build()
+pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth"); solver = importlib.import_module(PKG + ".solver")
+names = ["P0 load+linearise", "P1 condense (propagate + MFMA SYRK)", "P2 augment", "P3 cholesky", "P4a schur build",
+         "P4b box-QP (BPP)", "P5 back-subst", "P6 simulate", "output"]
+cfg = pkg.paper_config()
+for wl, B in (("hover", 256), ("takeoff", 256), ("hover", 4096)):
+    X = synth.make_batch(cfg, min(B, 256), workload=wl)
+    if B > 256: X = np.tile(X, (B // 256, 1))
+    m = solver.BatchedVSMPC(cfg, device=0, max_batch=B)
+    st = m.phase_cycles(X).astype(np.int64)
+    d = np.diff(st[:, :10], axis=1)
+    tot = st[:, 9] - st[:, 0]
+    print(f"== {wl} batch {B}: total cycles/instance median {np.median(tot):.0f} (s_memtime ticks), span of launch {(st[:,9].max()-st[:,0].min())}")
+    for i, n in enumerate(names):
+        print(f"  {n:38s} median {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f}  share {100*np.median(d[:, i])/np.median(tot):5.1f}%")
+    sub = ["P1 propagate (wave 0)", "P1 barrier wait", "P1 MFMA", "P3 diag tile", "P3 panel solve", "P3 trailing update"]
+    for i, n in enumerate(sub):
+        print(f"    {n:36s} median {np.median(st[:, 10 + i]):9.0f}")
+    m.close()
