@@ -99,22 +99,22 @@ struct Jet {
 
 // move blocking (constraintsVSMPC.cpp:89-128)
 template <class D>
-VS_HD int joint_block_of_stage(int k) { return k < D::HC ? k : D::HC - 1; }
+VS_HD constexpr int joint_block_of_stage(int k) { return k < D::HC ? k : D::HC - 1; }
 template <class D>
-VS_HD int throttle_block_of_stage(int k) {
+VS_HD constexpr int throttle_block_of_stage(int k) {
     return k < D::NS ? 0 : (k < D::HC ? k - (D::NS - 1) : D::HC - D::NS);
 }
 
 // Internal condensed column order: [U_0..U_{HC-1} | v_1..v_{NVB-1} | v_0 | gradient | pad].
 // v_0 goes last so that the 20-tick throttle hold (constraintsVSMPC.cpp:351) pins the trailing block.
 template <class D>
-VS_HD int v_block_of_internal(int q) {  // q in [0, NV): internal throttle index -> reference block
+VS_HD constexpr int v_block_of_internal(int q) {  // q in [0, NV): internal throttle index -> reference block
     const int b = q >> 2;
     return b < D::NVB - 1 ? b + 1 : 0;
 }
 // first stage at which internal column c becomes non-zero in the sensitivity recursion
 template <class D>
-VS_HD int col_first_stage(int c) {
+VS_HD constexpr int col_first_stage(int c) {
     if (c < D::NU) return c >> 3;
     if (c < D::NZ) {
         const int b = v_block_of_internal<D>(c - D::NU);
@@ -124,7 +124,7 @@ VS_HD int col_first_stage(int c) {
     return 1 << 20;
 }
 template <class D>
-VS_HD int tile_first_stage(int t) {
+VS_HD constexpr int tile_first_stage(int t) {
     int s = 1 << 20;
     for (int c = 16 * t; c < 16 * t + 16; ++c) {
         const int f = col_first_stage<D>(c);
@@ -133,6 +133,35 @@ VS_HD int tile_first_stage(int t) {
     return s;
 }
 
-VS_HD int wrow(int r) { return r < 12 ? r : r + 8; }  // weighted-row index -> state row
+VS_HD constexpr int wrow(int r) { return r < 12 ? r : r + 8; }  // weighted-row index -> state row
+
+// Compile-time table of the lower-triangular 16x16 tiles: (row tile, column tile, first stage at which
+// the tile of C = sum_k Y_k^T Y_k becomes non-zero), SORTED by that stage and padded to a multiple of 4
+// with never-active dummies.  Entry s is owned by wavefront s % 4, slot s / 4, so at every stage the
+// active slots of a wavefront form a prefix and the four wavefronts carry the same number of them (+-1).
+template <class D>
+struct TileTab {
+    static constexpr int NPAD = ((D::NTRI + 3) / 4) * 4;
+    int ti[NPAD];
+    int tj[NPAD];
+    int ts[NPAD];
+    constexpr TileTab() : ti{}, tj{}, ts{} {
+        int t = 0;
+        for (int i = 0; i < D::NT; ++i)
+            for (int j = 0; j <= i; ++j, ++t) {
+                ti[t] = i;
+                tj[t] = j;
+                const int a = tile_first_stage<D>(i), b = tile_first_stage<D>(j);
+                ts[t] = a > b ? a : b;
+            }
+        for (; t < NPAD; ++t) { ti[t] = 0; tj[t] = 0; ts[t] = 1 << 20; }
+        for (int a = 1; a < D::NTRI; ++a) {  // stable insertion sort by first stage
+            const int ki = ti[a], kj = tj[a], ks = ts[a];
+            int b = a - 1;
+            while (b >= 0 && ts[b] > ks) { ti[b + 1] = ti[b]; tj[b + 1] = tj[b]; ts[b + 1] = ts[b]; --b; }
+            ti[b + 1] = ki; tj[b + 1] = kj; ts[b + 1] = ks;
+        }
+    }
+};
 
 }  // namespace vsmpc

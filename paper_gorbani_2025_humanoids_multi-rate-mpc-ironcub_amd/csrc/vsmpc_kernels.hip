@@ -6,11 +6,12 @@
 //   P0 linearise   A, Bj, Bt, c in LDS                       (systemDynamicsVSMPC.cpp:79-103,288-319,384-429)
 //   P1 condense    sensitivity recursion in registers: thread (half, col) carries the linear-momentum
 //                  half (p, h_lin, e_pos | T, Tdot) or the angular half (rpy, h_ang, e_rpy | T, Tdot) of
-//                  one condensed column; two nodes (36 weighted rows) per pass;
+//                  one condensed column; two nodes (36 weighted rows = 9 exact MFMA k-steps) per pass;
 //                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
-//   P3 cholesky    blocked right-looking LL^T on 16x16 LDS tiles, trailing updates on MFMA
+//   P3 cholesky    right-looking LL^T on 16x16 LDS tiles: one wavefront factors a whole panel (diagonal tile
+//                  and the rows below it, lane = row, pivots broadcast with v_readlane), trailing updates on MFMA
 //   P4 box QP      free back-substitution first; only if a throttle bound is violated: Schur complement
 //                  on the warped throttles + block principal pivoting in one wavefront
 //                                                            (constraintsVSMPC.cpp:338-365)
@@ -20,6 +21,12 @@
 //
 // FP64 throughout.  The un-condensed KKT system the reference hands to OSQP has condition number
 // ~1e12; the condensed Hessian factored here is benign (1e2..1e3).
+//
+// Measured on MI355X (profiles/r01_microbench_*.txt): v_mfma_f64_16x16x4_f64 issues every 64 cycles per
+// SIMD (77.7 TFLOP/s chip-wide, already with one wavefront per SIMD); FP64 VALU work does not hide under
+// it (shared FP64 datapath); one FP64 FMA costs ~5.7 cycles for a lone wavefront, v_readlane pair + FMA
+// ~21.6.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
+// streams carry nothing but operand loads.
 #include "vsmpc_device.hpp"
 #include "vsmpc_launch.hpp"
 
@@ -30,13 +37,16 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int BLOCK = 256;
 constexpr int NWAVES = BLOCK / 64;
 
+template <class D>
+__device__ constexpr TileTab<D> kTileTab{};
+
 VS_DEV double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) and 1/d: hardware seed + two Newton steps (full double precision to ~2 ulp)
+// 1/sqrt(d) and 1/d: hardware seed + Newton steps (full double precision to ~2 ulp)
 VS_DEV double fast_rsqrt(double d) {
     double y = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
@@ -69,7 +79,9 @@ struct Smem {
     static constexpr int oSvec = oSv + D::NV * (D::NV + 1);
     static constexpr int oV = oSvec + D::NV;
     static constexpr int oX = oV + D::NV;
-    static constexpr int oFlags = oX + D::NXS;       // 4 doubles worth of int flags
+    static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
+    static constexpr int oDt = oF + NX * D::N;       // per-stage dt (copied out of the kernel arguments once)
+    static constexpr int oFlags = oDt + MAX_STAGES;  // 4 doubles worth of int flags
     static constexpr int oEllV = oFlags + 4;         // P6: sparse rows of A, 8 entries per state row
     static constexpr int oEllC = oEllV + NX * 8;     // (ints, 8 per row -> NX*4 doubles)
     static constexpr int oY = (oEllC + NX * 4 + 3) & ~3;
@@ -220,6 +232,183 @@ VS_DEV double input_cost_term(const DevCfg& cfg, const double* __restrict__ sIn,
 }
 
 // ------------------------------------------------------------------------------------------------
+// One SYRK pass of P1 for the first NACT slots of this wavefront, NKS k-steps of 4 rows: branch-free so
+// that the compiler can count outstanding LDS loads; operands of k-step ks+1 are requested before the
+// matrix-core chain of k-step ks is issued.
+// ------------------------------------------------------------------------------------------------
+template <class D, int TPW, int NACT, int NKS>
+VS_DEV void syrk_pass(d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW], int bufoff) {
+    const double* a[NACT];
+    const double* b[NACT];
+#pragma unroll
+    for (int q = 0; q < NACT; ++q) { a[q] = pa[q] + bufoff; b[q] = pb[q] + bufoff; }
+    double av[2][NACT], bv[2][NACT];
+#pragma unroll
+    for (int q = 0; q < NACT; ++q) { av[0][q] = a[q][0]; bv[0][q] = b[q][0]; }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) {
+#pragma unroll
+            for (int q = 0; q < NACT; ++q) {
+                av[(ks + 1) & 1][q] = a[q][(ks + 1) * 4 * D::YS];
+                bv[(ks + 1) & 1][q] = b[q][(ks + 1) * 4 * D::YS];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the next step's loads ahead of this step's MFMA chain
+#pragma unroll
+        for (int q = 0; q < NACT; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks & 1][q], bv[ks & 1][q], acc[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P3 panel factorisation by ONE wavefront, branch-free: lane l owns panel rows 16p + l (slot 0; lanes 0..15
+// are the diagonal tile) and, if TWO, 16p + 64 + l (slot 1).  Pivot-column entries are broadcast with
+// v_readlane; each broadcast feeds the updates of both slots.  NPIV < 16 only for the last panel, whose
+// remaining rows (gradient row, padding) are carried along as ordinary panel rows.
+// Returns non-zero if a pivot was not positive.
+// ------------------------------------------------------------------------------------------------
+template <class D, bool TWO, int NPIV>
+VS_DEV int panel_factor(double* __restrict__ sM, double* __restrict__ sInvD, int p, int lane) {
+    const int r0 = 16 * p + lane, r1 = r0 + 64;
+    const bool ok0 = r0 < D::NP, ok1 = TWO && (r1 < D::NP);
+    double* T0 = sM + tile_off<D>(ok0 ? (r0 >> 4) : p, p) + (r0 & 15) * 17;
+    double* T1 = sM + tile_off<D>(ok1 ? (r1 >> 4) : p, p) + (r1 & 15) * 17;
+    double a0[16], a1[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        a0[c] = T0[c];  // rows beyond the matrix read an in-range tile; their results are never stored
+        a1[c] = TWO ? T1[c] : 0.0;
+    }
+    int bad = 0;
+    double myinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPIV; ++j) {
+        const double d = readlane_f64(a0[j], j);
+        bad |= !(d > 0.0);
+        const double inv = fast_rsqrt(d);
+        myinv = (lane == j) ? inv : myinv;
+        const double l0 = a0[j] * inv;
+        a0[j] = l0;
+        double l1 = 0.0;
+        if constexpr (TWO) { l1 = a1[j] * inv; a1[j] = l1; }
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            const double lcj = readlane_f64(l0, c);
+            a0[c] = fma(-l0, lcj, a0[c]);
+            if constexpr (TWO) a1[c] = fma(-l1, lcj, a1[c]);
+        }
+    }
+    if (ok0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T0[c] = (lane >= 16 || c <= lane) ? a0[c] : 0.0;
+    }
+    if constexpr (TWO) {
+        if (ok1) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) T1[c] = a1[c];
+        }
+    }
+    if (lane < NPIV) sInvD[16 * p + lane] = myinv;
+    return bad;
+}
+
+template <class D, int TPW, int NKS, int NACT = TPW>
+VS_DEV void syrk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW],
+                          int bufoff) {
+    if constexpr (NACT >= 1) {
+        if (nact == NACT) syrk_pass<D, TPW, NACT, NKS>(acc, pa, pb, bufoff);
+        else syrk_dispatch<D, TPW, NKS, NACT - 1>(nact, acc, pa, pb, bufoff);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P2 + P3 for wavefront W, straight-line: the panel index and the tile table are compile-time, so every
+// "does this tile take part" decision folds away and every LDS offset is an immediate.
+//   P2  input-cost terms (joint weights, throttle coupling, gradient row) are added to the SYRK
+//       accumulators in registers;
+//   P3  right-looking blocked Cholesky with a register-resident trailing matrix: a tile goes to LDS exactly
+//       once, when its tile column becomes the panel; wavefront 0 factors the panel (panel_factor), then
+//       every wavefront updates the tiles it owns with four v_mfma_f64_16x16x4_f64 per tile.
+// All four instantiations execute the same number of workgroup barriers.
+// ------------------------------------------------------------------------------------------------
+template <class D, int TPW, int W>
+VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
+                          const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
+                          int lane, int crow, int lrow) {
+    constexpr TileTab<D> tab{};
+    constexpr int PVT = D::NU >> 4;
+    // ---- P2
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = q * NWAVES + W;
+        if (t < D::NTRI && (tab.ti[t] == tab.tj[t] || tab.ti[t] >= PVT)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[q][r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * tab.ti[t] + (lane >> 4) + 4 * r,
+                                                16 * tab.tj[t] + (lane & 15));
+        }
+    }
+    // ---- P3: tile column 0 goes to LDS; every later column is stored by the update that completes it
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = q * NWAVES + W;
+        if (t < D::NTRI && tab.tj[t] == 0) {
+            double* T = sM + tile_off<D>(tab.ti[t], 0) + crow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < D::NT; ++p) {
+        if (W == 0) {
+            constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
+            int bad;
+            if (p == D::NT - 1) bad = panel_factor<D, false, NPIV_LAST>(sM, sInvD, p, lane);
+            else if (16 * p + 64 < D::NP) bad = panel_factor<D, true, 16>(sM, sInvD, p, lane);
+            else bad = panel_factor<D, false, 16>(sM, sInvD, p, lane);
+            if (bad && lane == 0) sFlags[0] = 1;
+        }
+        __syncthreads();
+        if (p + 1 < D::NT) {
+            // trailing update M_ij -= L_ip L_jp^T for the tiles right of the panel: operands first, then the chains
+            double la[TPW][4], lb[TPW][4];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = q * NWAVES + W;
+                if (t < D::NTRI && tab.tj[t] > p) {
+                    const double* Lip = sM + tile_off<D>(tab.ti[t], p) + lrow;
+                    const double* Ljp = sM + tile_off<D>(tab.tj[t], p) + lrow;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) { la[q][ks] = -Lip[4 * ks]; lb[q][ks] = Ljp[4 * ks]; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = q * NWAVES + W;
+                if (t < D::NTRI && tab.tj[t] > p) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q][ks], lb[q][ks], acc[q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = q * NWAVES + W;
+                if (t < D::NTRI && tab.tj[t] == p + 1) {  // this tile column is the next panel: hand it to LDS
+                    double* T = sM + tile_off<D>(tab.ti[t], p + 1) + crow;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the solve kernel
 // ------------------------------------------------------------------------------------------------
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
@@ -242,13 +431,13 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     do {                                                             \
         if constexpr (STAMPS) t_mark = __builtin_amdgcn_s_memtime(); \
     } while (0)
-#define VS_TOC(i)                                                                    \
-    do {                                                                             \
-        if constexpr (STAMPS) {                                                      \
-            const unsigned long long t_now = __builtin_amdgcn_s_memtime();           \
-            t_acc[i] += t_now - t_mark;                                              \
-            t_mark = t_now;                                                          \
-        }                                                                            \
+#define VS_TOC(i)                                                          \
+    do {                                                                   \
+        if constexpr (STAMPS) {                                            \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+            t_acc[i] += t_now - t_mark;                                    \
+            t_mark = t_now;                                                \
+        }                                                                  \
     } while (0)
     using S = Smem<D>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -265,7 +454,9 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     double* sSvec = smem + S::oSvec;
     double* sV = smem + S::oV;
     double* sX = smem + S::oX;
-    int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);  // [0]=numerical failure, [1]=status, [2]=iters, [3]=bound violated
+    double* sF = smem + S::oF;
+    double* sDt = smem + S::oDt;
+    int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);  // [0] numerical failure, [1] status, [2] iters, [3] bound violated
     double* sEllV = smem + S::oEllV;
     int* sEllC = reinterpret_cast<int*>(smem + S::oEllC);
     double* sY = smem + S::oY;
@@ -273,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
     const int inst = blockIdx.x;
     if (inst >= batch) return;
 
@@ -281,6 +472,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     // ---------------------------------------------------------------- P0
     for (int i = tid; i < D::NIN; i += BLOCK) sIn[i] = in[size_t(inst) * D::NIN + i];
     if (tid < 4) sFlags[tid] = 0;
+    if (tid < D::N) sDt[tid] = cfg.dt[tid];
     __syncthreads();
     p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, BLOCK);
 
@@ -289,30 +481,20 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     // tiles of the lower triangle are dealt round-robin to the four wavefronts: tile t -> wave t%4, slot t/4
     constexpr int TPW = (D::NTRI + NWAVES - 1) / NWAVES;
     d4 acc[TPW];
-    int offA[TPW], offB[TPW], tstart[TPW], ti[TPW], tj[TPW];
+    int ti[TPW], tj[TPW], tstart[TPW];  // scalar (wave-uniform) tile coordinates from the compile-time table
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-        const int t = q * NWAVES + wave;
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        ti[q] = i;
-        tj[q] = t - i * (i + 1) / 2;
-        if (t < D::NTRI) {
-            const int a = tile_first_stage<D>(ti[q]), b = tile_first_stage<D>(tj[q]);
-            tstart[q] = a > b ? a : b;
-        } else {
-            ti[q] = tj[q] = 0;
-            tstart[q] = 1 << 20;
-        }
-        offA[q] = 16 * ti[q];
-        offB[q] = 16 * tj[q];
+        const int t = q * NWAVES + wave;  // entry of the stage-sorted table (padded with never-active dummies)
+        ti[q] = kTileTab<D>.ti[t];
+        tj[q] = kTileTab<D>.tj[t];
+        tstart[q] = kTileTab<D>.ts[t];
     }
 
     {
         // thread (half, col): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy);
         // both carry the jet states (T, Tdot) of their column.  Same code, different coefficient rows.
-        const int half = tid >> 7;
+        const int half = wave >> 1;  // scalar
         const int col = tid & 127;
         const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
         const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
@@ -355,18 +537,34 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
             bT[i] = kind == 1 ? (i == comp ? sBt[(12 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[12 + i] : 0.0);
             bTd[i] = kind == 1 ? (i == comp ? sBt[(16 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[16 + i] : 0.0);
         }
+        const double aff = kind == 2 ? 1.0 : 0.0;
         double sqx[3], sqh[3], sqe[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { sqx[r] = cfg.sq[yx0 + r]; sqh[r] = cfg.sq[yh0 + r]; sqe[r] = cfg.sq[ye0 + r]; }
 
+        // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step and the Y
+        // buffer enter as immediate offsets of ds_read_b64
+        const int ylane = (lane >> 4) * D::YS + (lane & 15);
+        const double* pa[TPW];
+        const double* pb[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            pa[q] = sY + ylane + 16 * ti[q];
+            pb[q] = sY + ylane + 16 * tj[q];
+        }
+
         constexpr int NPASS = (D::N + 1) / 2;
+        constexpr int BUFSZ = S::YROWS * D::YS;
+#pragma unroll 1
         for (int m = 0; m < NPASS; ++m) {
-            double* Yb = sY + (m & 1) * S::YROWS * D::YS;
+            const int bufoff = (m & 1) * BUFSZ;
+            double* Yb = sY + bufoff;
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
+#pragma unroll 1
             for (int par = 0; par < nnodes; ++par) {
                 const int k = 2 * m + par;  // stage k -> node k+1
-                const double dt = cfg.dt[k];
+                const double dt = sDt[k];
                 const bool actJ = (kind == 0 && joint_block_of_stage<D>(k) == blk) || kind == 2;
                 const bool actT = (kind == 1 && throttle_block_of_stage<D>(k) == blk) || kind == 2;
                 double dx[3], dh[3], de[3], dT[4], dTd[4];
@@ -395,14 +593,12 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
                 for (int i = 0; i < 4; ++i) { Ts[i] += dt * dT[i]; Tds[i] += dt * dTd[i]; }
                 // Y rows of this node: sqrt(Q) (S_k - xref_k on the affine column); column map costsVSMPC.cpp:191-200
                 const int rc = k < D::NS ? 0 : k - D::NS;
+                const double* xr = sIn + VSMPC_IN_XREF + rc * 12;  // uniform address: LDS broadcast
                 double* Yn = Yb + 18 * par * D::YS + col;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    double vx = xs[r], vh = hs[r];
-                    if (kind == 2) {
-                        vx -= sIn[VSMPC_IN_XREF + rc * 12 + yx0 + r];
-                        vh -= sIn[VSMPC_IN_XREF + rc * 12 + yh0 + r];
-                    }
+                    const double vx = fma(-aff, xr[yx0 + r], xs[r]);  // aff = 1 on the affine column, else 0
+                    const double vh = fma(-aff, xr[yh0 + r], hs[r]);
                     Yn[(yx0 + r) * D::YS] = sqx[r] * vx;
                     Yn[(yh0 + r) * D::YS] = sqh[r] * vh;
                     Yn[(ye0 + r) * D::YS] = sqe[r] * es[r];
@@ -416,22 +612,11 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
             // C += Y^T Y over this pass: D = A*B, A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n].
             // Columns that are not active yet are exactly zero, so skipping a tile is only an optimisation.
             const int last_stage = 2 * m + nnodes - 1;
-            const int nks = nnodes == 2 ? 9 : 5;
-            bool act[TPW];
+            int nact = 0;  // scalar: the table is sorted by first stage, so the active slots are a prefix
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) act[q] = last_stage >= tstart[q];
-            for (int ks = 0; ks < nks; ++ks) {
-                const double* yrow = Yb + (4 * ks + (lane >> 4)) * D::YS + (lane & 15);
-                double av[TPW], bv[TPW];
-#pragma unroll
-                for (int q = 0; q < TPW; ++q) {
-                    av[q] = yrow[offA[q]];
-                    bv[q] = yrow[offB[q]];
-                }
-#pragma unroll
-                for (int q = 0; q < TPW; ++q)
-                    if (act[q]) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[q], 0, 0, 0);
-            }
+            for (int q = 0; q < TPW; ++q) nact += (last_stage >= tstart[q]) ? 1 : 0;
+            if (nnodes == 2) syrk_dispatch<D, TPW, 9>(nact, acc, pa, pb, bufoff);
+            else syrk_dispatch<D, TPW, 5>(nact, acc, pa, pb, bufoff);
             VS_TOC(2);
             // one barrier per pass: the next pass writes the other Y buffer
         }
@@ -439,114 +624,40 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     __syncthreads();
     VS_STAMP(2);
 
-    // ---------------------------------------------------------------- P2 augment: M = C + R, gradient row
-    // (the tile storage reuses the Y buffers: every wave is past its last Y read at the barrier above)
+    // ---------------------------------------------------------------- P2 + P3 (wave-specialised, see cholesky_wave)
+    constexpr int PVT = D::NU >> 4;  // first tile row that contains a throttle row
+    const int crow = (lane >> 4) * 17 + (lane & 15);  // C/D fragment: row (lane>>4)+4r, column lane&15
+    const int lrow = (lane & 15) * 17 + (lane >> 4);  // A/B fragment: row lane&15, k = lane>>4
+    if (dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation
+        d4 tmp[TPW];
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        if (q * NWAVES + wave < D::NTRI) {
-            double* T = sM + tile_off<D>(ti[q], tj[q]);
+        for (int q = 0; q < TPW; ++q) {
+            tmp[q] = acc[q];
+            if (q * NWAVES + wave < D::NTRI) {
+                if (ti[q] == tj[q] || ti[q] >= PVT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) T[((lane >> 4) + 4 * r) * 17 + (lane & 15)] = acc[q][r];
+                    for (int r = 0; r < 4; ++r)
+                        tmp[q][r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * ti[q] + (lane >> 4) + 4 * r,
+                                                        16 * tj[q] + (lane & 15));
+                }
+                double* T = sM + tile_off<D>(ti[q], tj[q]) + crow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[4 * r * 17] = tmp[q][r];
+            }
         }
-    }
-    __syncthreads();
-    if (tid < D::NU) sM[lower_at<D>(tid, tid)] += cfg.wj[tid & 7];
-    for (int e = tid; e < D::NV * D::NV; e += BLOCK) {
-        const int r = e / D::NV, c = e % D::NV;
-        if (c <= r) {
-            const double v = input_cost_term<D>(cfg, sIn, sVprev, D::NU + r, D::NU + c);
-            if (v != 0.0) sM[lower_at<D>(D::NU + r, D::NU + c)] += v;
-        }
-    }
-    __syncthreads();
-    if (tid < D::NZ) sM[lower_at<D>(D::NZ, tid)] += input_cost_term<D>(cfg, sIn, sVprev, D::NZ, tid);
-    __syncthreads();
-    if (dbgM != nullptr) {
+        __syncthreads();
         for (int e = tid; e < D::NP * D::NP; e += BLOCK) {
             const int gr = e / D::NP, gc = e % D::NP;
             dbgM[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? sM[lower_at<D>(gr, gc)] : 0.0;
         }
         __syncthreads();
     }
-
     VS_STAMP(3);
-    // ---------------------------------------------------------------- P3 blocked Cholesky (first NZ pivots)
-    for (int p = 0; p < D::NT; ++p) {
-        const int npiv = (D::NZ - 16 * p) < 16 ? (D::NZ - 16 * p) : 16;
-        double* Tpp = sM + tile_off<D>(p, p);
-        VS_TIC();
-        if (wave == 0) {
-            // lane r (mod 16) owns row r of the diagonal tile; pivots broadcast with v_readlane
-            const int r = lane & 15;
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = Tpp[r * 17 + c];
-            int bad = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (j < npiv) {
-                    const double d = readlane_f64(a[j], j);
-                    bad |= !(d > 0.0);
-                    const double inv = fast_rsqrt(d);
-                    const double lj = a[j] * inv;
-                    a[j] = lj;
-                    if (lane == 0) sInvD[16 * p + j] = inv;
-#pragma unroll
-                    for (int c = j + 1; c < 16; ++c) {
-                        const double lcj = readlane_f64(lj, c);
-                        a[c] -= lj * lcj;
-                    }
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) Tpp[r * 17 + c] = (c <= r) ? a[c] : 0.0;
-            }
-            if (bad && lane == 0) sFlags[0] = 1;
-        }
-        __syncthreads();
-        VS_TOC(3);
-        if (p + 1 < D::NT) {
-            // panel solve: one thread per row below the diagonal tile, X L_pp^T = A
-            const int nrows = 16 * (D::NT - 1 - p);
-            if (tid < nrows) {
-                double* T = sM + tile_off<D>(p + 1 + (tid >> 4), p) + (tid & 15) * 17;
-                double x[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    double v = T[j];
-#pragma unroll
-                    for (int c = 0; c < j; ++c) v -= x[c] * Tpp[j * 17 + c];
-                    x[j] = v * sInvD[16 * p + j];
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) T[j] = x[j];
-            }
-            __syncthreads();
-            VS_TOC(4);
-            // trailing update M_ij -= L_ip L_jp^T, p < j <= i, on the matrix cores
-            const int mm = D::NT - 1 - p;
-            const int npairs = mm * (mm + 1) / 2;
-            for (int q = wave; q < npairs; q += NWAVES) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= q) ++ii;
-                const int jj = q - ii * (ii + 1) / 2;
-                const int i = p + 1 + ii, j = p + 1 + jj;
-                double* Tij = sM + tile_off<D>(i, j);
-                const double* Lip = sM + tile_off<D>(i, p) + (lane & 15) * 17 + (lane >> 4);
-                const double* Ljp = sM + tile_off<D>(j, p) + (lane & 15) * 17 + (lane >> 4);
-                d4 c4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c4[r] = Tij[((lane >> 4) + 4 * r) * 17 + (lane & 15)];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lip[4 * ks], Ljp[4 * ks], c4, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tij[((lane >> 4) + 4 * r) * 17 + (lane & 15)] = c4[r];
-            }
-            __syncthreads();
-            VS_TOC(5);
-        }
+    switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
+        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        default: cholesky_wave<D, TPW, 3>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
     }
     if (dbgL != nullptr) {
         for (int e = tid; e < D::NP * D::NP; e += BLOCK) {
@@ -567,49 +678,49 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     constexpr int PV = D::NU >> 4;  // first tile that contains a throttle row
     if (tid < D::NP) {
         sW[tid] = tid < D::NZ ? -sM[lower_at<D>(D::NZ, tid)] : 0.0;
-        sZ[tid] = 0.0;
+        sZ[tid] = (hold && tid >= D::NZ - 4 && tid < D::NZ) ? sVprev[tid - (D::NZ - 4)] : 0.0;
     }
-    __syncthreads();
-    if (tid < 4 && hold) sZ[D::NZ - 4 + tid] = sVprev[tid];
     __syncthreads();
 
     // one tile step of the sweep; `prescribed` = throttles already fixed in sZ
     auto sweep_tile = [&](int p, bool prescribed) {
         if (wave == 0) {
             const int j = lane & 15;  // lane j owns column j of L_pp
-            const double* Tpp = sM + tile_off<D>(p, p);
+            const int gj = 16 * p + j;
+            const double* Tpp = sM + tile_off<D>(p, p) + j;
             double colv[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) colv[k] = (k >= j) ? Tpp[k * 17 + j] : 0.0;
-            double w = sW[16 * p + j];
-            const double myinv = sInvD[16 * p + j];
-            const double zfix = sZ[16 * p + j];
+            for (int k = 0; k < 16; ++k) colv[k] = Tpp[k * 17];  // entries k < j are zero (stored upper part)
+            double w = sW[gj];
+            // z_j = w_j * inv_eff + zadd: solved rows use 1/L_jj, prescribed rows (pinned or already fixed
+            // throttles, gradient row, padding) use inv_eff = 0 and their value; branch-free in the chain
+            const bool fix = (gj >= D::NZ) || (gj >= D::NU && (prescribed || (hold && gj >= D::NZ - 4)));
+            const double inv_eff = fix ? 0.0 : sInvD[gj];
+            const double zadd = (fix && gj < D::NZ) ? sZ[gj] : 0.0;
             double z = 0.0;
 #pragma unroll
             for (int k = 15; k >= 0; --k) {
-                const int gk = 16 * p + k;  // wave-uniform
-                double zk;
-                if (gk >= D::NZ) zk = 0.0;
-                else if (gk >= D::NU && (prescribed || (hold && gk >= D::NZ - 4))) zk = readlane_f64(zfix, k);
-                else zk = readlane_f64(w * myinv, k);
-                if (j == k) z = zk;
-                if (j < k) w -= colv[k] * zk;
+                const double zk = readlane_f64(fma(w, inv_eff, zadd), k);
+                z = (j == k) ? zk : z;
+                w = fma(-colv[k], zk, w);  // lanes j >= k: colv is zero or w is no longer used
             }
-            if (lane < 16) sZ[16 * p + j] = z;
+            if (lane < 16) sZ[gj] = z;
         }
         __syncthreads();
         if (p > 0) {
             if (tid < 16 * p) {
                 const double* T = sM + tile_off<D>(p, tid >> 4) + (tid & 15);
+                const double* zp = sZ + 16 * p;
                 double a2 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a2 += T[k * 17] * sZ[16 * p + k];
+                for (int k = 0; k < 16; ++k) a2 += T[k * 17] * zp[k];
                 sW[tid] -= a2;
             }
             __syncthreads();
         }
     };
 
+#pragma unroll 1
     for (int p = D::NT - 1; p >= PV; --p) sweep_tile(p, false);
     if (wave == 0) {
         const bool valid = lane < D::NV;
@@ -722,9 +833,11 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         }
         __syncthreads();
         VS_STAMP(6);
+#pragma unroll 1
         for (int p = D::NT - 1; p >= 0; --p) sweep_tile(p, true);
     } else {
         VS_STAMP(6);
+#pragma unroll 1
         for (int p = PV - 1; p >= 0; --p) sweep_tile(p, false);
     }
     if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
@@ -732,42 +845,44 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 
     VS_STAMP(7);
     // ---------------------------------------------------------------- P6 forward simulation + outputs
+    // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c
+    for (int e = tid; e < NX * D::N; e += BLOCK) {
+        const int k = e / NX, r = e - k * NX;
+        const int jb = joint_block_of_stage<D>(k);
+        const int tb = throttle_block_of_stage<D>(k);
+        const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
+        double f = sC[r];
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) f += sBj[r * NJ + c] * sZ[NJ * jb + c];
+#pragma unroll
+        for (int c = 0; c < NTH; ++c) f += sBt[r * NTH + c] * sV[vq + c];
+        sF[e] = f;
+    }
+    if (wave == 0 && lane < NX) {
+        // sparse image of row `lane` of A (at most 7 structural non-zeros per row), 8 slots
+        int n = 0;
+        for (int c = 0; c < NX; ++c) {
+            const double v = sA[lane * NX + c];
+            if (v != 0.0 && n < 8) { sEllV[lane * 8 + n] = v; sEllC[lane * 8 + n] = c; ++n; }
+        }
+        for (; n < 8; ++n) { sEllV[lane * 8 + n] = 0.0; sEllC[lane * 8 + n] = 0; }
+    }
+    __syncthreads();
     if (wave == 0) {
         const int r = lane < NX ? lane : NX - 1;
-        // sparse image of row r of A (at most 7 structural non-zeros per row), 8 slots
-        {
-            int n = 0;
-            for (int c = 0; c < NX; ++c) {
-                const double v = sA[r * NX + c];
-                if (v != 0.0 && n < 8 && lane < NX) { sEllV[r * 8 + n] = v; sEllC[r * 8 + n] = c; ++n; }
-            }
-            for (; n < 8; ++n)
-                if (lane < NX) { sEllV[r * 8 + n] = 0.0; sEllC[r * 8 + n] = 0; }
-        }
-        double ev[8], bjrow[NJ], btrow[NTH];
+        double ev[8];
         int ec[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ev[e] = sEllV[r * 8 + e]; ec[e] = sEllC[r * 8 + e]; }
-#pragma unroll
-        for (int c = 0; c < NJ; ++c) bjrow[c] = sBj[r * NJ + c];
-#pragma unroll
-        for (int c = 0; c < NTH; ++c) btrow[c] = sBt[r * NTH + c];
-        const double cr = sC[r];
         double x = sIn[VSMPC_IN_X0 + r];
         if (lane < NX) sX[lane] = x;
+#pragma unroll 1
         for (int k = 0; k < D::N; ++k) {
-            const int jb = joint_block_of_stage<D>(k);
-            const int tb = throttle_block_of_stage<D>(k);
-            const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
             const double* xk = sX + NX * k;  // written by this wavefront in the previous iteration (in-order LDS)
-            double d = cr;
+            double d = sF[NX * k + r];
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += ev[e] * xk[ec[e]];
-#pragma unroll
-            for (int c = 0; c < NJ; ++c) d += bjrow[c] * sZ[NJ * jb + c];
-#pragma unroll
-            for (int c = 0; c < NTH; ++c) d += btrow[c] * sV[vq + c];
-            x += cfg.dt[k] * d;
+            x += sDt[k] * d;
             if (lane < NX) sX[NX * (k + 1) + lane] = x;
         }
     }
