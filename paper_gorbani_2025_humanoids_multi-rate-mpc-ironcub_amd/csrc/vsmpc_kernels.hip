@@ -470,7 +470,12 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 
     VS_STAMP(0);
     // ---------------------------------------------------------------- P0
-    for (int i = tid; i < D::NIN; i += BLOCK) sIn[i] = in[size_t(inst) * D::NIN + i];
+    {   // 16 B per lane: the record stride (NIN doubles) and the LDS base are multiples of 16 B
+        static_assert(D::NIN % 2 == 0 && D::NVAR % 2 == 0 && D::NXS % 2 == 0 && D::NU % 2 == 0, "double2 I/O");
+        const double2* in2 = reinterpret_cast<const double2*>(in + size_t(inst) * D::NIN);
+        double2* sIn2 = reinterpret_cast<double2*>(sIn);
+        for (int i = tid; i < D::NIN / 2; i += BLOCK) sIn2[i] = in2[i];
+    }
     if (tid < 4) sFlags[tid] = 0;
     if (tid < D::N) sDt[tid] = cfg.dt[tid];
     __syncthreads();
@@ -890,13 +895,13 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     VS_STAMP(8);
 
     if (xout != nullptr) {
-        double* xo = xout + size_t(inst) * D::NVAR;
-        for (int i = tid; i < D::NXS; i += BLOCK) xo[i] = sX[i];
-        for (int i = tid; i < D::NU; i += BLOCK) xo[D::NXS + i] = sZ[i];
-        if (tid < D::NV) {  // reference order v_0..v_{NVB-1}
-            const int b = tid >> 2, c = tid & 3;
+        double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
+        for (int i = tid; i < D::NXS / 2; i += BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
+        for (int i = tid; i < D::NU / 2; i += BLOCK) xo[D::NXS / 2 + i] = make_double2(sZ[2 * i], sZ[2 * i + 1]);
+        if (tid < D::NV / 2) {  // reference order v_0..v_{NVB-1}
+            const int e = 2 * tid, b = e >> 2, c = e & 3;
             const int q = b == 0 ? D::NV - 4 + c : 4 * (b - 1) + c;
-            xo[D::NXS + D::NU + tid] = sV[q];
+            xo[(D::NXS + D::NU) / 2 + tid] = make_double2(sV[q], sV[q + 1]);
         }
     }
     if (fmout != nullptr && tid < VSMPC_FM_SIZE) {

@@ -5,9 +5,10 @@
 Writes profiles/<tag>_kernel_stats.csv (the rocprofv3 --kernel-trace --stats summary, trimmed to the
 top kernels), profiles/<tag>_summary.md and, when PMC passes are given, updates
 profiles/hbm_traffic.json with the HBM bytes per launch of the solve kernel:
-    bytes = (FETCH_SIZE + WRITE_SIZE) * 1024          (rocprofv3 reports KiB; MI355X_MICROARCH.md "HBM")
-FETCH_SIZE is NOT doubled here: the guide's x2 correction is calibrated for 16 B/lane streaming
-reads only, and a large share of this kernel's fetches are instruction fetches.
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      (rocprofv3 reports KiB; MI355X_MICROARCH.md "HBM":
+on gfx950 FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream, WRITE_SIZE is exact for
+16 B/lane stores; the kernel's global loads and stores are 16 B per lane).  The uncorrected sum is kept too.
+A large share of the fetches are instruction fetches, for which the x2 is an upper bound.
 """
 import csv
 import glob
@@ -60,13 +61,14 @@ def main():
             rr = [r for r in csv.DictReader(open(one(os.path.join(d, "**", "*_counter_collection.csv"))))
                   if "solve_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
             vals[name] = statistics.median(float(r["Counter_Value"]) for r in rr)
-        total = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+        total = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+        raw = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
         lines += ["", "## HBM traffic (separate --pmc passes)", "",
                   f"- FETCH_SIZE median {vals['FETCH_SIZE']:.0f} KiB / launch", f"- WRITE_SIZE median {vals['WRITE_SIZE']:.0f} KiB / launch",
-                  f"- bytes per launch = (FETCH+WRITE)*1024 = {total:.0f}"]
+                  f"- bytes per launch = (2*FETCH+WRITE)*1024 = {total:.0f}  (uncorrected (FETCH+WRITE)*1024 = {raw:.0f})"]
         tpath = os.path.join(out_dir, "hbm_traffic.json")
         db = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        db[key] = {"bytes_per_launch": total, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "tag": tag}
+        db[key] = {"bytes_per_launch": total, "bytes_per_launch_uncorrected": raw, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "tag": tag}
         json.dump(db, open(tpath, "w"), indent=1, sort_keys=True)
     open(os.path.join(out_dir, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
