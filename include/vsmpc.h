@@ -142,6 +142,26 @@ int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, dou
 int vsmpc_linearize_batch(vsmpc_handle* h, const double* in, int batch, double* A, double* Bj,
                           double* Bt, double* c, double* dt);
 
+/* Kinematics-derived inputs on the device (rows a3/a4 of the path): LinearMomentumDynamicVS::computeLambdaLin
+ * (systemDynamicsVSMPC.cpp:321-350), AngularMomentumDynamicVS::computeLambdaAng + getRelativeJacobianCoM
+ * (:159-226, "unfiltered" option) and the locked inertia of updateRPY (:128-130), from the raw Robot quantities.
+ * kin[batch][VSMPC_KIN_SIZE] host buffer; out[batch][57] = Lambda_lin,B (24) | Lambda_ang,B (24) | I_G (9), all
+ * row-major.  If `records` is not NULL (host, [batch][n_in]) the three fields are also written into the input
+ * records at VSMPC_IN_LLIN / VSMPC_IN_LANG / VSMPC_IN_INERTIA. */
+#define VSMPC_KIN_NJ 23        /* robot joints (MPCPyBindings.cpp:43) */
+#define VSMPC_KIN_WRB 0        /*   9 wR_b row-major                                                   */
+#define VSMPC_KIN_THRUST 9     /*   4 Robot::getJetThrusts                                             */
+#define VSMPC_KIN_AXES 13      /*  12 Robot::getMatrixOfJetAxes 4x3                                    */
+#define VSMPC_KIN_ARMS 25      /*  12 Robot::getMatrixOfJetArms 4x3                                    */
+#define VSMPC_KIN_JREL 37      /* 276 getRelativeJacobianJetsBodyFrame()[i].bottomRows(3), 4 x (3x23)   */
+#define VSMPC_KIN_JFRAME 313   /* 276 getJacobian(jet).topRightCorner(3,23), 4 x (3x23)                 */
+#define VSMPC_KIN_JCOM 589     /*  69 getJacobianCoM().topRightCorner(3,23)                            */
+#define VSMPC_KIN_MB 658       /*  36 getMassMatrix().block(0,0,6,6) row-major                         */
+#define VSMPC_KIN_R 694        /*   3 p_CoM - p_base                                                   */
+#define VSMPC_KIN_SIZE 697
+#define VSMPC_KIN_OUT 57
+int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double* out, double* records);
+
 /* Debug/parity: the reference-ordered dense QP of ONE instance, assembled on the host from the
  * DEVICE linearisation exactly as IMPCProblem::update stacks it (IMPCProblem.cpp:150-194):
  * H[nVar*nVar], g[nVar], Ac[nCon*nVar] (row-major), lo[nCon], hi[nCon]. */

@@ -564,6 +564,53 @@ def first_move_vector(cfg: Config, x: np.ndarray) -> np.ndarray:
     return np.concatenate([o["delta_q"], o["v0"], o["throttle"], o["thrust"], o["thrust_dot"]])
 
 
+# --------------------------------------------------------------------------------------
+# Kinematics-derived inputs (rows a3/a4 of SURVEY.md 8a): Lambda_lin,B, Lambda_ang,B, I_G from the raw
+# Robot quantities.  Record layout KIN_* = include/vsmpc.h VSMPC_KIN_*; nJ = 23 robot joints.
+# --------------------------------------------------------------------------------------
+KIN_NJ = 23
+KIN_WRB = 0        # 9   wR_b row-major
+KIN_THRUST = 9     # 4   Robot::getJetThrusts
+KIN_AXES = 13      # 12  Robot::getMatrixOfJetAxes, 4x3
+KIN_ARMS = 25      # 12  Robot::getMatrixOfJetArms, 4x3
+KIN_JREL = 37      # 276 Robot::getRelativeJacobianJetsBodyFrame()[i].bottomRows(3), 4 x (3x23) row-major
+KIN_JFRAME = 313   # 276 Robot::getJacobian(jet).topRightCorner(3, nJ), 4 x (3x23)
+KIN_JCOM = 589     # 69  Robot::getJacobianCoM().topRightCorner(3, nJ)
+KIN_MB = 658       # 36  Robot::getMassMatrix().block(0,0,6,6) row-major
+KIN_R = 694        # 3   p_CoM - p_base
+KIN_SIZE = 697
+KIN_JOINT_OFFSET = 3  # systemDynamicsVSMPC.cpp:348 (middleCols(3, 8)); the name-based selector of :202-205 picks the same columns
+
+
+def kinematics_terms(kin: np.ndarray):
+    """Lambda_lin,B (3x8), Lambda_ang,B (3x8) ["unfiltered" option, vs_mcp_config.xml:21], I_G (3x3)."""
+    nJ = KIN_NJ
+    R = kin[KIN_WRB:KIN_WRB + 9].reshape(3, 3)
+    T = kin[KIN_THRUST:KIN_THRUST + 4]
+    axes = kin[KIN_AXES:KIN_AXES + 12].reshape(4, 3)
+    arms = kin[KIN_ARMS:KIN_ARMS + 12].reshape(4, 3)
+    Jrel = kin[KIN_JREL:KIN_JREL + 4 * 3 * nJ].reshape(4, 3, nJ)
+    Jfr = kin[KIN_JFRAME:KIN_JFRAME + 4 * 3 * nJ].reshape(4, 3, nJ)
+    Jcom = kin[KIN_JCOM:KIN_JCOM + 3 * nJ].reshape(3, nJ)
+    Mb = kin[KIN_MB:KIN_MB + 36].reshape(6, 6)
+    r = kin[KIN_R:KIN_R + 3]
+    lam_lin = np.zeros((3, nJ))
+    lam_ang = np.zeros((3, nJ))
+    for i in range(4):
+        Sa = from_vec_to_skew(R.T @ axes[i])
+        lam_lin -= T[i] * Sa @ Jrel[i]                                       # systemDynamicsVSMPC.cpp:339-345
+        JrelCoM = R.T @ (Jfr[i] - Jcom)                                      # :208-226 (getRelativeJacobianCoM)
+        lam_ang -= T[i] * Sa @ JrelCoM                                       # :169-174
+        lam_ang -= T[i] * from_vec_to_skew(R.T @ arms[i]) @ Sa @ Jrel[i]     # :176-183
+    X = np.zeros((6, 6))                                                     # iDynTree Transform::asAdjointTransform
+    X[0:3, 0:3] = R
+    X[0:3, 3:6] = from_vec_to_skew(r) @ R
+    X[3:6, 3:6] = R
+    inertia = (X.T @ Mb @ X)[3:6, 3:6]                                       # :128-130
+    o = KIN_JOINT_OFFSET
+    return lam_lin[:, o:o + 8].copy(), lam_ang[:, o:o + 8].copy(), inertia
+
+
 def solve_instance(cfg: Config, inp: np.ndarray):
     H, g, Ac, lo, hi = assemble_dense(cfg, inp)
     x, y, iters = solve_exact(cfg, H, g, Ac, lo, hi)

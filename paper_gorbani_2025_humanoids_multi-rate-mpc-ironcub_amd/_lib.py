@@ -15,7 +15,7 @@ EXPORTS = (
     "vsmpc_create", "vsmpc_destroy", "vsmpc_num_variables", "vsmpc_num_constraints", "vsmpc_input_doubles",
     "vsmpc_max_batch", "vsmpc_solve_batch", "vsmpc_solve_batch_device", "vsmpc_linearize_batch",
     "vsmpc_assemble_dense", "vsmpc_condensed_dim", "vsmpc_debug_condensed", "vsmpc_timing_begin",
-    "vsmpc_timing_end", "vsmpc_strerror", "vsmpc_kernel_name", "vsmpc_debug_phase_cycles",
+    "vsmpc_timing_end", "vsmpc_strerror", "vsmpc_kernel_name", "vsmpc_debug_phase_cycles", "vsmpc_kinematics_batch",
 )
 
 _lib = None
@@ -57,6 +57,8 @@ def load():
     lib.vsmpc_assemble_dense.restype = c_int
     lib.vsmpc_debug_condensed.argtypes = [vp, dp, dp, dp]
     lib.vsmpc_debug_condensed.restype = c_int
+    lib.vsmpc_kinematics_batch.argtypes = [vp, dp, c_int, dp, dp]
+    lib.vsmpc_kinematics_batch.restype = c_int
     lib.vsmpc_debug_phase_cycles.argtypes = [vp, dp, c_int, vp]
     lib.vsmpc_debug_phase_cycles.restype = c_int
     lib.vsmpc_timing_begin.argtypes = [vp, vp]

@@ -317,6 +317,33 @@ int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, doub
     return VSMPC_OK;
 }
 
+int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double* out, double* records) {
+    if (h == nullptr || kin == nullptr || out == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch == 0) return VSMPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    double* d_kin = nullptr;
+    double* d_out = nullptr;
+    hipError_t e = hipMalloc(&d_kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_out, size_t(batch) * VSMPC_KIN_OUT * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_kin, kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_kinematics(d_kin, batch, d_out, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, size_t(batch) * VSMPC_KIN_OUT * sizeof(double), hipMemcpyDeviceToHost);
+    if (d_kin) (void)hipFree(d_kin);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(e, "vsmpc_kinematics_batch");
+    if (records != nullptr) {  // patch the three fields of the input records (host side, layout bookkeeping only)
+        for (int b = 0; b < batch; ++b) {
+            double* rec = records + size_t(b) * h->n_in;
+            const double* o = out + size_t(b) * VSMPC_KIN_OUT;
+            memcpy(rec + VSMPC_IN_LLIN, o, 24 * sizeof(double));
+            memcpy(rec + VSMPC_IN_LANG, o + 24, 24 * sizeof(double));
+            memcpy(rec + VSMPC_IN_INERTIA, o + 48, 9 * sizeof(double));
+        }
+    }
+    return VSMPC_OK;
+}
+
 int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsigned long long* stamps16) {
     if (h == nullptr || in == nullptr || stamps16 == nullptr || batch <= 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;

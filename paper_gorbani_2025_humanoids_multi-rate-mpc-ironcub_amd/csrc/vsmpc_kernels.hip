@@ -930,6 +930,91 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// kinematics-derived inputs (vsmpc_kinematics_batch): Lambda_lin,B, Lambda_ang,B, I_G per instance.
+// HBM-bound (5.6 KB in, 0.46 KB out per instance): one wavefront per instance stages the record in LDS with
+// 16 B/lane loads, 57 lanes compute one output element each.
+//   computeLambdaLin          systemDynamicsVSMPC.cpp:321-350
+//   computeLambdaAng          systemDynamicsVSMPC.cpp:159-206 ("unfiltered"), getRelativeJacobianCoM :208-226
+//   locked inertia I_G        systemDynamicsVSMPC.cpp:128-130 (iDynTree adjoint X = [R, S(r)R; 0, R])
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict__ kin, int batch,
+                                                        double* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double s[VSMPC_KIN_SIZE + 1];
+    __shared__ double sRa[12], sRr[12];  // R^T a_i, R^T r_i
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= batch) return;
+    const double* rec = kin + size_t(b) * VSMPC_KIN_SIZE;
+    // the record stride (697 doubles) is odd, so 16 B alignment alternates: peel one element where needed
+    const int head = (reinterpret_cast<size_t>(rec) & 15) ? 1 : 0;
+    if (lane == 0 && head) s[0] = rec[0];
+    const double2* r2 = reinterpret_cast<const double2*>(rec + head);
+    const int n2 = (VSMPC_KIN_SIZE - head) / 2;
+    for (int i = lane; i < n2; i += 64) {
+        const double2 v = r2[i];
+        s[head + 2 * i] = v.x;
+        s[head + 2 * i + 1] = v.y;
+    }
+    if (lane == 0 && ((VSMPC_KIN_SIZE - head) & 1)) s[VSMPC_KIN_SIZE - 1] = rec[VSMPC_KIN_SIZE - 1];
+    __syncthreads();
+    const double* R = s + VSMPC_KIN_WRB;
+    if (lane < 24) {  // R^T a_i and R^T r_i
+        const int which = lane / 12, e = lane % 12, i = e / 3, c = e % 3;
+        const double* v = s + (which ? VSMPC_KIN_ARMS : VSMPC_KIN_AXES) + 3 * i;
+        const double val = R[c] * v[0] + R[3 + c] * v[1] + R[6 + c] * v[2];
+        (which ? sRr : sRa)[e] = val;
+    }
+    __syncthreads();
+    constexpr int NJq = VSMPC_KIN_NJ, OFF = 3;  // controlled joints = robot joints 3..10 (systemDynamicsVSMPC.cpp:348)
+    double res = 0.0;
+    if (lane < 48) {
+        const bool ang = lane >= 24;
+        const int e = lane % 24, r = e >> 3, col = OFF + (e & 7);
+        for (int i = 0; i < 4; ++i) {
+            const double T = s[VSMPC_KIN_THRUST + i];
+            const double* a = sRa + 3 * i;
+            const double* Jrel = s + VSMPC_KIN_JREL + i * 3 * NJq;
+            // w = S(a) * Jrel[:, col]  (skew: FlightControlUtils.cpp:77-85)
+            const double j0 = Jrel[col], j1 = Jrel[NJq + col], j2 = Jrel[2 * NJq + col];
+            const double w0 = -a[2] * j1 + a[1] * j2, w1 = a[2] * j0 - a[0] * j2, w2 = -a[1] * j0 + a[0] * j1;
+            if (!ang) {
+                res -= T * (r == 0 ? w0 : (r == 1 ? w1 : w2));
+            } else {
+                const double* Jf = s + VSMPC_KIN_JFRAME + i * 3 * NJq;
+                const double* Jc = s + VSMPC_KIN_JCOM;
+                const double d0 = Jf[col] - Jc[col], d1 = Jf[NJq + col] - Jc[NJq + col], d2 = Jf[2 * NJq + col] - Jc[2 * NJq + col];
+                const double g0 = R[0] * d0 + R[3] * d1 + R[6] * d2;  // R^T (J_frame - J_CoM)
+                const double g1 = R[1] * d0 + R[4] * d1 + R[7] * d2;
+                const double g2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+                const double u0 = -a[2] * g1 + a[1] * g2, u1 = a[2] * g0 - a[0] * g2, u2 = -a[1] * g0 + a[0] * g1;
+                const double* q = sRr + 3 * i;  // S(R^T r_i) * w
+                const double z0 = -q[2] * w1 + q[1] * w2, z1 = q[2] * w0 - q[0] * w2, z2 = -q[1] * w0 + q[0] * w1;
+                res -= T * ((r == 0 ? u0 : (r == 1 ? u1 : u2)) + (r == 0 ? z0 : (r == 1 ? z1 : z2)));
+            }
+        }
+    } else if (lane < 57) {
+        // I_G = [S(r)R; R]^T M_b [S(r)R; R], element (i, j)
+        const int e = lane - 48, i = e / 3, j = e % 3;
+        const double* rr = s + VSMPC_KIN_R;
+        const double* M = s + VSMPC_KIN_MB;
+        double Xi[6], Xj[6];  // columns i and j of the 6x3 matrix [S(r)R; R]
+        for (int k = 0; k < 3; ++k) { Xi[3 + k] = R[3 * k + i]; Xj[3 + k] = R[3 * k + j]; }
+        Xi[0] = -rr[2] * Xi[4] + rr[1] * Xi[5]; Xi[1] = rr[2] * Xi[3] - rr[0] * Xi[5]; Xi[2] = -rr[1] * Xi[3] + rr[0] * Xi[4];
+        Xj[0] = -rr[2] * Xj[4] + rr[1] * Xj[5]; Xj[1] = rr[2] * Xj[3] - rr[0] * Xj[5]; Xj[2] = -rr[1] * Xj[3] + rr[0] * Xj[4];
+        for (int a = 0; a < 6; ++a) {
+            double t = 0.0;
+            for (int c = 0; c < 6; ++c) t += M[6 * a + c] * Xj[c];
+            res += Xi[a] * t;
+        }
+    }
+    if (lane < VSMPC_KIN_OUT) out[size_t(b) * VSMPC_KIN_OUT + lane] = res;
+}
+
+hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(kinematics_kernel, dim3(batch), dim3(64), 0, stream, d_kin, batch, d_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 template <class D, bool STAMPS>

@@ -19,4 +19,6 @@ hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int 
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                             double* Bt, double* c, hipStream_t stream);
 
+hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipStream_t stream);
+
 }  // namespace vsmpc

@@ -36,6 +36,20 @@ IN_QERR = 153
 IN_HOLD = 161
 IN_XREF = 162
 
+# kinematics record of vsmpc_kinematics_batch (VSMPC_KIN_* in include/vsmpc.h)
+KIN_NJ = 23
+KIN_WRB = 0
+KIN_THRUST = 9
+KIN_AXES = 13
+KIN_ARMS = 25
+KIN_JREL = 37
+KIN_JFRAME = 313
+KIN_JCOM = 589
+KIN_MB = 658
+KIN_R = 694
+KIN_SIZE = 697
+KIN_OUT = 57
+
 # first-move block (24 doubles): dq(8) v0(4) throttle%(4) T1(4) Tdot1(4)
 FM_DQ = 0
 FM_V0 = 8

@@ -126,6 +126,19 @@ class BatchedVSMPC:
         return M, Lf
 
 
+    def kinematics(self, kin: np.ndarray, records: np.ndarray | None = None):
+        """Lambda_lin,B, Lambda_ang,B, I_G from raw Robot quantities (vsmpc_kinematics_batch); optionally patches
+        them into `records` in place."""
+        kin = np.ascontiguousarray(kin, dtype=np.float64)
+        if kin.ndim != 2 or kin.shape[1] != L.KIN_SIZE:
+            raise ValueError(f"kin must be [batch, {L.KIN_SIZE}]")
+        out = np.empty((kin.shape[0], L.KIN_OUT))
+        if records is not None:
+            assert records.flags["C_CONTIGUOUS"] and records.shape == (kin.shape[0], self.n_in)
+        _lib.check(self.lib.vsmpc_kinematics_batch(self._h, _ptr(kin), kin.shape[0], _ptr(out), _ptr(records)),
+                   "vsmpc_kinematics_batch")
+        return out[:, 0:24].reshape(-1, 3, 8), out[:, 24:48].reshape(-1, 3, 8), out[:, 48:57].reshape(-1, 3, 3)
+
     def phase_cycles(self, inputs: np.ndarray) -> np.ndarray:
         """Diagnostic build only: per-instance s_memtime stamps at the phase boundaries, [batch, 16]."""
         inputs = np.ascontiguousarray(inputs, dtype=np.float64)

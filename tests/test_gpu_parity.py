@@ -265,3 +265,32 @@ def test_wrapper_consumes_only_when_solved(solver_mod, synth, layout):
     np.testing.assert_array_equal(w.getJointsReferencePosition(), q1)   # previous commands persist
     np.testing.assert_array_equal(w.getThrottleReference(), thr)
     assert not w.update(rec[:10])
+
+
+def test_kinematics_terms_match_oracle(mpc, ref, synth, layout):
+    """Rows a3/a4: Lambda_lin,B, Lambda_ang,B (unfiltered) and I_G from raw Robot quantities."""
+    rng = np.random.default_rng(7)
+    B = 37                                             # odd count: record stride 697 doubles alternates 16 B alignment
+    kin = rng.normal(size=(B, layout.KIN_SIZE))
+    for b in range(B):                                 # a proper rotation, positive thrusts, SPD base mass matrix
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        kin[b, layout.KIN_WRB:layout.KIN_WRB + 9] = (q * np.sign(np.linalg.det(q))).reshape(-1)
+        kin[b, layout.KIN_THRUST:layout.KIN_THRUST + 4] = rng.uniform(20, 220, size=4)
+        a = rng.normal(size=(6, 6))
+        kin[b, layout.KIN_MB:layout.KIN_MB + 36] = (a @ a.T + 6 * np.eye(6)).reshape(-1)
+    recs = synth.make_batch(layout.paper_config(), B, workload="hover")
+    before = recs.copy()
+    Llin, Lang, IG = mpc.kinematics(kin, recs)
+    for b in range(B):
+        l1, l2, ig = ref.kinematics_terms(kin[b])
+        assert relerr(Llin[b], l1) < 1e-13 and relerr(Lang[b], l2) < 1e-13 and relerr(IG[b], ig) < 1e-13
+        np.testing.assert_array_equal(recs[b, layout.IN_LLIN:layout.IN_LLIN + 24], Llin[b].reshape(-1))
+        np.testing.assert_array_equal(recs[b, layout.IN_LANG:layout.IN_LANG + 24], Lang[b].reshape(-1))
+        np.testing.assert_array_equal(recs[b, layout.IN_INERTIA:layout.IN_INERTIA + 9], IG[b].reshape(-1))
+    untouched = np.ones(recs.shape[1], dtype=bool)
+    untouched[layout.IN_LLIN:layout.IN_LLIN + 48] = False
+    untouched[layout.IN_INERTIA:layout.IN_INERTIA + 9] = False
+    np.testing.assert_array_equal(recs[:, untouched], before[:, untouched])
+    # the patched records still solve (I_G symmetric positive definite here)
+    x, fm, st, it = mpc.solve(recs)
+    assert (st == layout.STATUS_SOLVED).all()

@@ -157,3 +157,28 @@ def test_algorithm_model_matches_oracle(ref, golden_paper, golden_h2x, which):
         assert status == 1
         assert np.abs(xm - gold["x"][i]).max() / max(1.0, np.abs(gold["x"][i]).max()) < 1e-10
         assert iters == int(gold["iters"][i])
+
+
+def test_kinematics_terms_closed_form(ref):
+    """Single jet, identity attitude: Lambda_lin = -T S(a) J_rel, Lambda_ang = -T (S(a)(J_f - J_c) + S(r) S(a) J_rel),
+    I_G = parallel-axis form of the base block (systemDynamicsVSMPC.cpp:128-130,159-226,321-350)."""
+    kin = np.zeros(ref.KIN_SIZE)
+    kin[ref.KIN_WRB:ref.KIN_WRB + 9] = np.eye(3).reshape(-1)
+    kin[ref.KIN_THRUST] = 100.0
+    kin[ref.KIN_AXES:ref.KIN_AXES + 3] = [0.0, 0.0, 1.0]
+    kin[ref.KIN_ARMS:ref.KIN_ARMS + 3] = [0.0, 0.3, 0.0]
+    col = ref.KIN_JOINT_OFFSET + 2
+    kin[ref.KIN_JREL + 0 * 23 + col] = 0.2               # J_rel,0[0, col]  (x row)
+    kin[ref.KIN_JFRAME + 1 * 23 + col] = 0.5             # J_frame,0[1, col]
+    kin[ref.KIN_JCOM + 1 * 23 + col] = 0.1               # J_CoM[1, col]
+    m, r = 70.0, np.array([0.0, 0.0, 0.2])
+    Mb = np.zeros((6, 6)); Mb[:3, :3] = m * np.eye(3); Mb[3:, 3:] = np.diag([8.0, 7.0, 2.0])
+    kin[ref.KIN_MB:ref.KIN_MB + 36] = Mb.reshape(-1)
+    kin[ref.KIN_R:ref.KIN_R + 3] = r
+    Llin, Lang, IG = ref.kinematics_terms(kin)
+    # S(e_z) [0.2,0,0]^T = [0, 0.2, 0]
+    np.testing.assert_allclose(Llin[:, 2], [0.0, -100.0 * 0.2, 0.0], atol=1e-13)
+    assert np.count_nonzero(Llin) == 1
+    # S(e_z)[0,0.4,0]^T = [-0.4,0,0]; S(r_arm) S(a) Jrel = [0,0.3,0] x [0,0.2,0] = 0
+    np.testing.assert_allclose(Lang[:, 2], [100.0 * 0.4, 0.0, 0.0], atol=1e-13)
+    np.testing.assert_allclose(IG, np.diag([8.0, 7.0, 2.0]) + m * (r @ r * np.eye(3) - np.outer(r, r)), atol=1e-12)
