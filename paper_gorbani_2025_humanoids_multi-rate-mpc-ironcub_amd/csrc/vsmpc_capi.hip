@@ -25,6 +25,7 @@ struct vsmpc_handle {
     int* d_iters;
     double* d_lin;  // A | Bj | Bt | c for max_batch instances
     double* d_dbg;  // M | L for one instance
+    double* d_ws;   // factor workspace for horizons whose factor does not fit LDS (max_batch instances)
     hipEvent_t ev0, ev1;
 };
 
@@ -129,6 +130,8 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     if (e == hipSuccess) e = hipMalloc(&h->d_iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_lin, B * (NX * NX + NX * NJ + NX * NTH + NX) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->d_dbg, size_t(2) * h->n_p * h->n_p * sizeof(double));
+    if (e == hipSuccess && variant_workspace_doubles(variant) > 0)
+        e = hipMalloc(&h->d_ws, B * variant_workspace_doubles(variant) * sizeof(double));
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -149,6 +152,7 @@ void vsmpc_destroy(vsmpc_handle* h) {
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->d_lin) (void)hipFree(h->d_lin);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
+    if (h->d_ws) (void)hipFree(h->d_ws);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -166,7 +170,7 @@ int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, dou
     if (h == nullptr || d_in == nullptr || d_status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
     if (batch == 0) return VSMPC_OK;
     HIP_TRY(launch_solve(h->variant, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
-                         nullptr, static_cast<hipStream_t>(stream)));
+                         nullptr, h->d_ws, static_cast<hipStream_t>(stream)));
     return VSMPC_OK;
 }
 
@@ -180,7 +184,7 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
     const size_t B = size_t(batch);
     HIP_TRY(hipMemcpyAsync(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                         nullptr, nullptr, s));
+                         nullptr, nullptr, h->d_ws, s));
     if (x) HIP_TRY(hipMemcpyAsync(x, h->d_x, B * h->n_var * sizeof(double), hipMemcpyDeviceToHost, s));
     if (first_move)
         HIP_TRY(hipMemcpyAsync(first_move, h->d_fm, B * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -310,7 +314,7 @@ int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, doub
     const size_t np2 = size_t(h->n_p) * h->n_p;
     HIP_TRY(hipMemcpy(h->d_in, in_one, h->n_in * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, 1, h->d_x, h->d_fm, h->d_status, h->d_iters, h->d_dbg,
-                         h->d_dbg + np2, nullptr, nullptr));
+                         h->d_dbg + np2, nullptr, h->d_ws, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     if (M) HIP_TRY(hipMemcpy(M, h->d_dbg, np2 * sizeof(double), hipMemcpyDeviceToHost));
     if (Lfac) HIP_TRY(hipMemcpy(Lfac, h->d_dbg + np2, np2 * sizeof(double), hipMemcpyDeviceToHost));
@@ -354,7 +358,7 @@ int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsig
     if (e == hipSuccess) e = hipMemcpy(h->d_in, in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3 && e == hipSuccess; ++rep)  // warm instruction caches, keep the last run
         e = launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                         nullptr, d_st, nullptr);
+                         nullptr, d_st, h->d_ws, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess)
         e = hipMemcpy(stamps16, d_st, size_t(batch) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);

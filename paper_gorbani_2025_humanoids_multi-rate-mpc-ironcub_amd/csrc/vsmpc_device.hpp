@@ -41,6 +41,16 @@ struct Dims {
     static constexpr int NCON = NXS + NTH * (N - NS + 1);
     static constexpr int YS = NP + 16;       // Y row stride (doubles): 16 mod 32 -> conflict-free b64 reads
     static constexpr int TS = 16 * 17;       // tile stride (16 rows, padded row stride 17)
+    // workgroup shape: the sensitivity recursion runs one condensed column per thread and per half (linear /
+    // angular), so the workgroup needs 2 * NP threads: 256 for the paper horizon, 512 for the 2x horizon
+    static constexpr int BLOCK = NP <= 128 ? 256 : 512;
+    static constexpr int NWAVES = BLOCK / 64;
+    static constexpr int PCOLS = BLOCK / 2;
+    static_assert(NP <= PCOLS, "one condensed column per thread pair");
+    // The factor's tiles live in LDS (reusing the two Y buffers) when they fit; otherwise (2x horizon: 120 tiles =
+    // 261 KB) they live in a per-instance global workspace that stays L2/Infinity-Cache resident, and Y is single-buffered.
+    static constexpr bool L_IN_LDS = (NTRI * TS) <= (2 * 36 * YS);
+    static constexpr size_t L_WORKSPACE_DOUBLES = L_IN_LDS ? 0 : size_t(NTRI) * TS;
     static_assert(N <= MAX_STAGES, "horizon too long");
     static_assert(NV <= 64, "throttle block must fit one wavefront");
 };
@@ -137,11 +147,11 @@ VS_HD constexpr int wrow(int r) { return r < 12 ? r : r + 8; }  // weighted-row 
 
 // Compile-time table of the lower-triangular 16x16 tiles: (row tile, column tile, first stage at which
 // the tile of C = sum_k Y_k^T Y_k becomes non-zero), SORTED by that stage and padded to a multiple of 4
-// with never-active dummies.  Entry s is owned by wavefront s % 4, slot s / 4, so at every stage the
+// with never-active dummies.  Entry s is owned by wavefront s % NWAVES, slot s / NWAVES, so at every stage the
 // active slots of a wavefront form a prefix and the four wavefronts carry the same number of them (+-1).
 template <class D>
 struct TileTab {
-    static constexpr int NPAD = ((D::NTRI + 3) / 4) * 4;
+    static constexpr int NPAD = ((D::NTRI + D::NWAVES - 1) / D::NWAVES) * D::NWAVES;
     int ti[NPAD];
     int tj[NPAD];
     int ts[NPAD];

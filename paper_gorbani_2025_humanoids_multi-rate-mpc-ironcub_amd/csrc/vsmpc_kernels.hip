@@ -34,8 +34,6 @@ namespace vsmpc {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int BLOCK = 256;
-constexpr int NWAVES = BLOCK / 64;
 
 template <class D>
 __device__ constexpr TileTab<D> kTileTab{};
@@ -86,9 +84,10 @@ struct Smem {
     static constexpr int oEllC = oEllV + NX * 8;     // (ints, 8 per row -> NX*4 doubles)
     static constexpr int oY = (oEllC + NX * 4 + 3) & ~3;
     static constexpr int YROWS = 36;                 // two nodes x 18 weighted rows = 9 exact MFMA k-steps
-    static constexpr int sizeY = 2 * YROWS * D::YS;  // double-buffered
+    static constexpr int NYBUF = D::L_IN_LDS ? 2 : 1; // double-buffered when the budget allows
+    static constexpr int sizeY = NYBUF * YROWS * D::YS;
     static constexpr int oM = oY;                    // the factor's tiles reuse the Y buffers (dead after P1)
-    static constexpr int sizeM = D::NTRI * D::TS;
+    static constexpr int sizeM = D::L_IN_LDS ? D::NTRI * D::TS : 0;
     static constexpr int total = oY + (sizeY > sizeM ? sizeY : sizeM);
     static constexpr size_t bytes = size_t(total) * sizeof(double);
 };
@@ -263,55 +262,110 @@ VS_DEV void syrk_pass(d4 (&acc)[TPW], const double* const (&pa)[TPW], const doub
 }
 
 // ------------------------------------------------------------------------------------------------
-// P3 panel factorisation by ONE wavefront, branch-free: lane l owns panel rows 16p + l (slot 0; lanes 0..15
-// are the diagonal tile) and, if TWO, 16p + 64 + l (slot 1).  Pivot-column entries are broadcast with
-// v_readlane; each broadcast feeds the updates of both slots.  NPIV < 16 only for the last panel, whose
-// remaining rows (gradient row, padding) are carried along as ordinary panel rows.
+// P3 panel factorisation by ONE wavefront, branch-free: lane l owns panel rows 16p + 64 s + l for the row slots
+// s = 0..NSLOT-1 (slot 0, lanes 0..15 = the diagonal tile).  Pivot-column entries are broadcast with v_readlane;
+// each broadcast feeds the updates of all slots.  NPIV < 16 only for the last panel, whose remaining rows
+// (gradient row, padding) are carried along as ordinary panel rows.  `Lb` is the tile storage of the factor
+// (LDS for the paper horizon, a global workspace for horizons whose factor does not fit LDS).
 // Returns non-zero if a pivot was not positive.
 // ------------------------------------------------------------------------------------------------
-template <class D, bool TWO, int NPIV>
-VS_DEV int panel_factor(double* __restrict__ sM, double* __restrict__ sInvD, int p, int lane) {
-    const int r0 = 16 * p + lane, r1 = r0 + 64;
-    const bool ok0 = r0 < D::NP, ok1 = TWO && (r1 < D::NP);
-    double* T0 = sM + tile_off<D>(ok0 ? (r0 >> 4) : p, p) + (r0 & 15) * 17;
-    double* T1 = sM + tile_off<D>(ok1 ? (r1 >> 4) : p, p) + (r1 & 15) * 17;
-    double a0[16], a1[16];
+template <class D, int NSLOT, int NPIV>
+VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane) {
+    double* T[NSLOT];
+    bool ok[NSLOT];
+    double a[NSLOT][16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        a0[c] = T0[c];  // rows beyond the matrix read an in-range tile; their results are never stored
-        a1[c] = TWO ? T1[c] : 0.0;
+    for (int s = 0; s < NSLOT; ++s) {
+        const int r = 16 * p + 64 * s + lane;
+        ok[s] = r < D::NP;
+        T[s] = Lb + tile_off<D>(ok[s] ? (r >> 4) : p, p) + (r & 15) * 17;  // rows beyond the matrix read an
+#pragma unroll                                                              // in-range tile and are never stored
+        for (int c = 0; c < 16; ++c) a[s][c] = T[s][c];
     }
     int bad = 0;
     double myinv = 0.0;
 #pragma unroll
     for (int j = 0; j < NPIV; ++j) {
-        const double d = readlane_f64(a0[j], j);
+        const double d = readlane_f64(a[0][j], j);
         bad |= !(d > 0.0);
         const double inv = fast_rsqrt(d);
         myinv = (lane == j) ? inv : myinv;
-        const double l0 = a0[j] * inv;
-        a0[j] = l0;
-        double l1 = 0.0;
-        if constexpr (TWO) { l1 = a1[j] * inv; a1[j] = l1; }
+        double l[NSLOT];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) { l[s] = a[s][j] * inv; a[s][j] = l[s]; }
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
-            const double lcj = readlane_f64(l0, c);
-            a0[c] = fma(-l0, lcj, a0[c]);
-            if constexpr (TWO) a1[c] = fma(-l1, lcj, a1[c]);
+            const double lcj = readlane_f64(l[0], c);
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) a[s][c] = fma(-l[s], lcj, a[s][c]);
         }
     }
-    if (ok0) {
+    if (ok[0]) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) T0[c] = (lane >= 16 || c <= lane) ? a0[c] : 0.0;
+        for (int c = 0; c < 16; ++c) T[0][c] = (lane >= 16 || c <= lane) ? a[0][c] : 0.0;
     }
-    if constexpr (TWO) {
-        if (ok1) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) T1[c] = a1[c];
+    for (int s = 1; s < NSLOT; ++s)
+        if (ok[s]) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) T[s][c] = a[s][c];
         }
-    }
     if (lane < NPIV) sInvD[16 * p + lane] = myinv;
     return bad;
+}
+
+// runtime-p wrapper (kept out of line for long horizons so that the unrolled panel loop stays small)
+template <class D>
+__device__ __attribute__((noinline)) int panel_factor_rt(double* Lb, double* sInvD, int p, int lane) {
+    constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
+    if (p == D::NT - 1) return panel_factor<D, 1, NPIV_LAST>(Lb, sInvD, p, lane);
+    const int rows = D::NP - 16 * p;
+    if (rows > 192) return panel_factor<D, 4, 16>(Lb, sInvD, p, lane);
+    if (rows > 128) return panel_factor<D, 3, 16>(Lb, sInvD, p, lane);
+    if (rows > 64) return panel_factor<D, 2, 16>(Lb, sInvD, p, lane);
+    return panel_factor<D, 1, 16>(Lb, sInvD, p, lane);
+}
+
+// Many tiles per wavefront (long horizons): the first NCH chunks of CH slots, branch-free; operands of the
+// next (k-step, chunk) are requested before the matrix-core chain of the current one.  Slots of an active chunk
+// that are not active yet multiply exact zeros.
+template <class D, int TPW, int CH, int NCH, int NKS>
+VS_DEV void syrk_chunks(d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW], int bufoff) {
+    double av[2][CH], bv[2][CH];
+    constexpr int NSTEP = NKS * NCH;
+#pragma unroll
+    for (int q = 0; q < CH; ++q) { av[0][q] = pa[q][bufoff]; bv[0][q] = pb[q][bufoff]; }
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int ks = st / NCH, ch = st % NCH;
+        if (st + 1 < NSTEP) {
+            const int ks1 = (st + 1) / NCH, ch1 = (st + 1) % NCH;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int qq = ch1 * CH + q;
+                if (qq < TPW) {
+                    av[(st + 1) & 1][q] = pa[qq][bufoff + ks1 * 4 * D::YS];
+                    bv[(st + 1) & 1][q] = pb[qq][bufoff + ks1 * 4 * D::YS];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int qq = ch * CH + q;
+            if (qq < TPW)
+                acc[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st & 1][q], bv[st & 1][q], acc[qq], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <class D, int TPW, int CH, int NKS, int NCH = (TPW + CH - 1) / CH>
+VS_DEV void syrk_chunk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TPW],
+                                const double* const (&pb)[TPW], int bufoff) {
+    if constexpr (NCH >= 1) {
+        if (nact > (NCH - 1) * CH) syrk_chunks<D, TPW, CH, NCH, NKS>(acc, pa, pb, bufoff);
+        else syrk_chunk_dispatch<D, TPW, CH, NKS, NCH - 1>(nact, acc, pa, pb, bufoff);
+    }
 }
 
 template <class D, int TPW, int NKS, int NACT = TPW>
@@ -342,7 +396,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
     // ---- P2
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int t = q * NWAVES + W;
+        const int t = q * D::NWAVES + W;
         if (t < D::NTRI && (tab.ti[t] == tab.tj[t] || tab.ti[t] >= PVT)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -353,31 +407,62 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
     // ---- P3: tile column 0 goes to LDS; every later column is stored by the update that completes it
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int t = q * NWAVES + W;
+        const int t = q * D::NWAVES + W;
         if (t < D::NTRI && tab.tj[t] == 0) {
             double* T = sM + tile_off<D>(tab.ti[t], 0) + crow;
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
         }
     }
+    if constexpr (!D::L_IN_LDS) __threadfence_block();
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < D::NT; ++p) {
         if (W == 0) {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
             int bad;
-            if (p == D::NT - 1) bad = panel_factor<D, false, NPIV_LAST>(sM, sInvD, p, lane);
-            else if (16 * p + 64 < D::NP) bad = panel_factor<D, true, 16>(sM, sInvD, p, lane);
-            else bad = panel_factor<D, false, 16>(sM, sInvD, p, lane);
+            if constexpr (D::L_IN_LDS) {
+                if (p == D::NT - 1) bad = panel_factor<D, 1, NPIV_LAST>(sM, sInvD, p, lane);
+                else if (16 * p + 64 < D::NP) bad = panel_factor<D, 2, 16>(sM, sInvD, p, lane);
+                else bad = panel_factor<D, 1, 16>(sM, sInvD, p, lane);
+            } else {
+                bad = panel_factor_rt<D>(sM, sInvD, p, lane);
+            }
             if (bad && lane == 0) sFlags[0] = 1;
         }
+        if constexpr (!D::L_IN_LDS) __threadfence_block();  // panel lives in global memory: order it for the other waves
         __syncthreads();
-        if (p + 1 < D::NT) {
+        if constexpr (TPW > 12) {
+            // long horizons (30 tiles per wavefront): tile by tile, operands straight from the (L2-resident) workspace
+            if (p + 1 < D::NT) {
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    const int t = q * D::NWAVES + W;
+                    if (t < D::NTRI && tab.tj[t] > p) {
+                        const double* Lip = sM + tile_off<D>(tab.ti[t], p) + lrow;
+                        const double* Ljp = sM + tile_off<D>(tab.tj[t], p) + lrow;
+                        double la1[4], lb1[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) { la1[ks] = -Lip[4 * ks]; lb1[ks] = Ljp[4 * ks]; }
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la1[ks], lb1[ks], acc[q], 0, 0, 0);
+                        if (tab.tj[t] == p + 1) {
+                            double* T = sM + tile_off<D>(tab.ti[t], p + 1) + crow;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        } else if (p + 1 < D::NT) {
             // trailing update M_ij -= L_ip L_jp^T for the tiles right of the panel: operands first, then the chains
             double la[TPW][4], lb[TPW][4];
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                const int t = q * NWAVES + W;
+                const int t = q * D::NWAVES + W;
                 if (t < D::NTRI && tab.tj[t] > p) {
                     const double* Lip = sM + tile_off<D>(tab.ti[t], p) + lrow;
                     const double* Ljp = sM + tile_off<D>(tab.tj[t], p) + lrow;
@@ -387,7 +472,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
             }
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                const int t = q * NWAVES + W;
+                const int t = q * D::NWAVES + W;
                 if (t < D::NTRI && tab.tj[t] > p) {
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
@@ -396,7 +481,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
             }
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                const int t = q * NWAVES + W;
+                const int t = q * D::NWAVES + W;
                 if (t < D::NTRI && tab.tj[t] == p + 1) {  // this tile column is the next panel: hand it to LDS
                     double* T = sM + tile_off<D>(tab.ti[t], p + 1) + crow;
 #pragma unroll
@@ -414,11 +499,12 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
 // `stamps` (its own buffer, never read by the kernel).  The shipped instantiation has STAMPS = false.
 template <class D, bool STAMPS>
-__global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
+__global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* __restrict__ xout, double* __restrict__ fmout,
                                                          int* __restrict__ status_out, int* __restrict__ iters_out,
                                                          double* __restrict__ dbgM, double* __restrict__ dbgL,
-                                                         unsigned long long* __restrict__ stamps) {
+                                                         unsigned long long* __restrict__ stamps,
+                                                         double* __restrict__ gLws) {
 #define VS_STAMP(i)                                                                         \
     do {                                                                                    \
         if constexpr (STAMPS) {                                                             \
@@ -460,13 +546,15 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     double* sEllV = smem + S::oEllV;
     int* sEllC = reinterpret_cast<int*>(smem + S::oEllC);
     double* sY = smem + S::oY;
-    double* sM = smem + S::oM;
+    double* sM = smem + S::oM;  // tile storage of the factor when it fits LDS
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
     const int inst = blockIdx.x;
     if (inst >= batch) return;
+    // tile storage of the factor: LDS, or this instance's slice of the global workspace
+    double* Lb = D::L_IN_LDS ? sM : gLws + size_t(inst) * D::L_WORKSPACE_DOUBLES;
 
     VS_STAMP(0);
     // ---------------------------------------------------------------- P0
@@ -474,23 +562,23 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         static_assert(D::NIN % 2 == 0 && D::NVAR % 2 == 0 && D::NXS % 2 == 0 && D::NU % 2 == 0, "double2 I/O");
         const double2* in2 = reinterpret_cast<const double2*>(in + size_t(inst) * D::NIN);
         double2* sIn2 = reinterpret_cast<double2*>(sIn);
-        for (int i = tid; i < D::NIN / 2; i += BLOCK) sIn2[i] = in2[i];
+        for (int i = tid; i < D::NIN / 2; i += D::BLOCK) sIn2[i] = in2[i];
     }
     if (tid < 4) sFlags[tid] = 0;
     if (tid < D::N) sDt[tid] = cfg.dt[tid];
     __syncthreads();
-    p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, BLOCK);
+    p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);
 
     VS_STAMP(1);
     // ---------------------------------------------------------------- P1 condense
     // tiles of the lower triangle are dealt round-robin to the four wavefronts: tile t -> wave t%4, slot t/4
-    constexpr int TPW = (D::NTRI + NWAVES - 1) / NWAVES;
+    constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
     d4 acc[TPW];
     int ti[TPW], tj[TPW], tstart[TPW];  // scalar (wave-uniform) tile coordinates from the compile-time table
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-        const int t = q * NWAVES + wave;  // entry of the stage-sorted table (padded with never-active dummies)
+        const int t = q * D::NWAVES + wave;  // entry of the stage-sorted table (padded with never-active dummies)
         ti[q] = kTileTab<D>.ti[t];
         tj[q] = kTileTab<D>.tj[t];
         tstart[q] = kTileTab<D>.ts[t];
@@ -499,8 +587,8 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     {
         // thread (half, col): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy);
         // both carry the jet states (T, Tdot) of their column.  Same code, different coefficient rows.
-        const int half = wave >> 1;  // scalar
-        const int col = tid & 127;
+        const int half = wave / (D::NWAVES / 2);  // scalar
+        const int col = tid % D::PCOLS;
         const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
         const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
         int kind = 3, blk = 0, comp = 0;  // 0 joint column, 1 throttle column, 2 affine column, 3 pad
@@ -562,7 +650,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         constexpr int BUFSZ = S::YROWS * D::YS;
 #pragma unroll 1
         for (int m = 0; m < NPASS; ++m) {
-            const int bufoff = (m & 1) * BUFSZ;
+            const int bufoff = (S::NYBUF == 2) ? (m & 1) * BUFSZ : 0;
             double* Yb = sY + bufoff;
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
@@ -610,7 +698,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
                 }
             }
             if (nnodes == 1)  // rows 18,19 of the last, single-node pass (k-step 4 reads rows 16..19)
-                for (int i = tid; i < 2 * D::YS; i += BLOCK) Yb[18 * D::YS + i] = 0.0;
+                for (int i = tid; i < 2 * D::YS; i += D::BLOCK) Yb[18 * D::YS + i] = 0.0;
             VS_TOC(0);
             __syncthreads();
             VS_TOC(1);
@@ -620,10 +708,16 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
             int nact = 0;  // scalar: the table is sorted by first stage, so the active slots are a prefix
 #pragma unroll
             for (int q = 0; q < TPW; ++q) nact += (last_stage >= tstart[q]) ? 1 : 0;
-            if (nnodes == 2) syrk_dispatch<D, TPW, 9>(nact, acc, pa, pb, bufoff);
-            else syrk_dispatch<D, TPW, 5>(nact, acc, pa, pb, bufoff);
+            if constexpr (TPW <= 12) {
+                if (nnodes == 2) syrk_dispatch<D, TPW, 9>(nact, acc, pa, pb, bufoff);
+                else syrk_dispatch<D, TPW, 5>(nact, acc, pa, pb, bufoff);
+            } else {
+                if (nnodes == 2) syrk_chunk_dispatch<D, TPW, 6, 9>(nact, acc, pa, pb, bufoff);
+                else syrk_chunk_dispatch<D, TPW, 6, 5>(nact, acc, pa, pb, bufoff);
+            }
             VS_TOC(2);
-            // one barrier per pass: the next pass writes the other Y buffer
+            // double-buffered Y: one barrier per pass (the next pass writes the other buffer); single buffer: two
+            if constexpr (S::NYBUF == 1) __syncthreads();
         }
     }
     __syncthreads();
@@ -638,36 +732,47 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             tmp[q] = acc[q];
-            if (q * NWAVES + wave < D::NTRI) {
+            if (q * D::NWAVES + wave < D::NTRI) {
                 if (ti[q] == tj[q] || ti[q] >= PVT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         tmp[q][r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * ti[q] + (lane >> 4) + 4 * r,
                                                         16 * tj[q] + (lane & 15));
                 }
-                double* T = sM + tile_off<D>(ti[q], tj[q]) + crow;
+                double* T = Lb + tile_off<D>(ti[q], tj[q]) + crow;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T[4 * r * 17] = tmp[q][r];
             }
         }
+        if constexpr (!D::L_IN_LDS) __threadfence_block();
         __syncthreads();
-        for (int e = tid; e < D::NP * D::NP; e += BLOCK) {
+        for (int e = tid; e < D::NP * D::NP; e += D::BLOCK) {
             const int gr = e / D::NP, gc = e % D::NP;
-            dbgM[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? sM[lower_at<D>(gr, gc)] : 0.0;
+            dbgM[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? Lb[lower_at<D>(gr, gc)] : 0.0;
         }
         __syncthreads();
     }
     VS_STAMP(3);
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-        default: cholesky_wave<D, TPW, 3>(cfg, acc, sM, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 3: cholesky_wave<D, TPW, 3>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        default:
+            if constexpr (D::NWAVES > 4) {
+                switch (wave) {
+                    case 4: cholesky_wave<D, TPW, 4>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+                    case 5: cholesky_wave<D, TPW, 5>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+                    case 6: cholesky_wave<D, TPW, 6>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+                    default: cholesky_wave<D, TPW, 7>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+                }
+            }
+            break;
     }
     if (dbgL != nullptr) {
-        for (int e = tid; e < D::NP * D::NP; e += BLOCK) {
+        for (int e = tid; e < D::NP * D::NP; e += D::BLOCK) {
             const int gr = e / D::NP, gc = e % D::NP;
-            dbgL[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? sM[lower_at<D>(gr, gc)] : 0.0;
+            dbgL[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? Lb[lower_at<D>(gr, gc)] : 0.0;
         }
         __syncthreads();
     }
@@ -682,7 +787,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     const bool hold = sIn[VSMPC_IN_HOLD] != 0.0;
     constexpr int PV = D::NU >> 4;  // first tile that contains a throttle row
     if (tid < D::NP) {
-        sW[tid] = tid < D::NZ ? -sM[lower_at<D>(D::NZ, tid)] : 0.0;
+        sW[tid] = tid < D::NZ ? -Lb[lower_at<D>(D::NZ, tid)] : 0.0;
         sZ[tid] = (hold && tid >= D::NZ - 4 && tid < D::NZ) ? sVprev[tid - (D::NZ - 4)] : 0.0;
     }
     __syncthreads();
@@ -692,7 +797,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         if (wave == 0) {
             const int j = lane & 15;  // lane j owns column j of L_pp
             const int gj = 16 * p + j;
-            const double* Tpp = sM + tile_off<D>(p, p) + j;
+            const double* Tpp = Lb + tile_off<D>(p, p) + j;
             double colv[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) colv[k] = Tpp[k * 17];  // entries k < j are zero (stored upper part)
@@ -714,7 +819,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
         __syncthreads();
         if (p > 0) {
             if (tid < 16 * p) {
-                const double* T = sM + tile_off<D>(p, tid >> 4) + (tid & 15);
+                const double* T = Lb + tile_off<D>(p, tid >> 4) + (tid & 15);
                 const double* zp = sZ + 16 * p;
                 double a2 = 0.0;
 #pragma unroll
@@ -742,21 +847,21 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 
     if (need_qp) {
         // Schur complement S = L22 L22^T, s = L22 (L^-1 g)_v
-        for (int e = tid; e < D::NV * D::NV; e += BLOCK) {
+        for (int e = tid; e < D::NV * D::NV; e += D::BLOCK) {
             const int r = e / D::NV, c = e % D::NV;
             const int kmax = r < c ? r : c;
             double sum = 0.0;
             for (int k = 0; k <= kmax; ++k)
-                sum += sM[lower_at<D>(D::NU + r, D::NU + k)] * sM[lower_at<D>(D::NU + c, D::NU + k)];
+                sum += Lb[lower_at<D>(D::NU + r, D::NU + k)] * Lb[lower_at<D>(D::NU + c, D::NU + k)];
             sSv[r * (D::NV + 1) + c] = sum;
         }
         if (tid < D::NV) {
             double sum = 0.0;
             for (int k = 0; k <= tid; ++k)
-                sum += sM[lower_at<D>(D::NU + tid, D::NU + k)] * sM[lower_at<D>(D::NZ, D::NU + k)];
+                sum += Lb[lower_at<D>(D::NU + tid, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
             sSvec[tid] = sum;
         }
-        if (tid < D::NP) sW[tid] = tid < D::NZ ? -sM[lower_at<D>(D::NZ, tid)] : 0.0;  // restart the sweep
+        if (tid < D::NP) sW[tid] = tid < D::NZ ? -Lb[lower_at<D>(D::NZ, tid)] : 0.0;  // restart the sweep
         __syncthreads();
 
         if (wave == 0) {
@@ -851,7 +956,7 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
     VS_STAMP(7);
     // ---------------------------------------------------------------- P6 forward simulation + outputs
     // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c
-    for (int e = tid; e < NX * D::N; e += BLOCK) {
+    for (int e = tid; e < NX * D::N; e += D::BLOCK) {
         const int k = e / NX, r = e - k * NX;
         const int jb = joint_block_of_stage<D>(k);
         const int tb = throttle_block_of_stage<D>(k);
@@ -896,8 +1001,8 @@ __global__ __launch_bounds__(BLOCK, 1) void solve_kernel(DevCfg cfg, const doubl
 
     if (xout != nullptr) {
         double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
-        for (int i = tid; i < D::NXS / 2; i += BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
-        for (int i = tid; i < D::NU / 2; i += BLOCK) xo[D::NXS / 2 + i] = make_double2(sZ[2 * i], sZ[2 * i + 1]);
+        for (int i = tid; i < D::NXS / 2; i += D::BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
+        for (int i = tid; i < D::NU / 2; i += D::BLOCK) xo[D::NXS / 2 + i] = make_double2(sZ[2 * i], sZ[2 * i + 1]);
         if (tid < D::NV / 2) {  // reference order v_0..v_{NVB-1}
             const int e = 2 * tid, b = e >> 2, c = e & 3;
             const int q = b == 0 ? D::NV - 4 + c : 4 * (b - 1) + c;
@@ -1020,7 +1125,8 @@ hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipS
 template <class D, bool STAMPS>
 static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
-                                 unsigned long long* stamps, hipStream_t stream) {
+                                 unsigned long long* stamps, double* ws, hipStream_t stream) {
+    if (!D::L_IN_LDS && ws == nullptr) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS>),
@@ -1028,8 +1134,8 @@ static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batc
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((solve_kernel<D, STAMPS>), dim3(batch), dim3(BLOCK), Smem<D>::bytes, stream, cfg, d_in, batch,
-                       d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
+    hipLaunchKernelGGL((solve_kernel<D, STAMPS>), dim3(batch), dim3(D::BLOCK), Smem<D>::bytes, stream, cfg, d_in, batch,
+                       d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps, ws);
     return hipGetLastError();
 }
 
@@ -1041,15 +1147,18 @@ static hipError_t launch_linearize_t(const DevCfg& cfg, const double* d_in, int 
 }
 
 using DimsPaper = Dims<17, 7, 12>;
+using DimsH2x = Dims<34, 14, 24>;  // BASELINE.json configs[4]: 2x horizon at halved fast-rate dt
 
 int select_variant(int n_iter, int n_iter_small, int control_horizon) {
     if (n_iter == 17 && n_iter_small == 7 && control_horizon == 12) return VARIANT_PAPER;
+    if (n_iter == 34 && n_iter_small == 14 && control_horizon == 24) return VARIANT_H2X;
     return VARIANT_NONE;
 }
 
 const char* variant_kernel_name(int variant) {
     switch (variant) {
         case VARIANT_PAPER: return "solve_kernel<Dims<17,7,12>>";
+        case VARIANT_H2X: return "solve_kernel<Dims<34,14,24>>";
         default: return "none";
     }
 }
@@ -1057,20 +1166,35 @@ const char* variant_kernel_name(int variant) {
 int variant_condensed_dim(int variant) {
     switch (variant) {
         case VARIANT_PAPER: return DimsPaper::NP;
+        case VARIANT_H2X: return DimsH2x::NP;
+        default: return 0;
+    }
+}
+
+size_t variant_workspace_doubles(int variant) {
+    switch (variant) {
+        case VARIANT_PAPER: return DimsPaper::L_WORKSPACE_DOUBLES;
+        case VARIANT_H2X: return DimsH2x::L_WORKSPACE_DOUBLES;
         default: return 0;
     }
 }
 
 hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                         int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
-                        hipStream_t stream) {
+                        double* ws, hipStream_t stream) {
     switch (variant) {
         case VARIANT_PAPER:
             if (stamps != nullptr)
                 return launch_solve_t<DimsPaper, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
-                                                       stamps, stream);
+                                                       stamps, ws, stream);
             return launch_solve_t<DimsPaper, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
-                                                    nullptr, stream);
+                                                    nullptr, ws, stream);
+        case VARIANT_H2X:
+            if (stamps != nullptr)
+                return launch_solve_t<DimsH2x, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
+                                                     ws, stream);
+            return launch_solve_t<DimsH2x, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, nullptr,
+                                                  ws, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1079,6 +1203,7 @@ hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, 
                             double* Bt, double* c, hipStream_t stream) {
     switch (variant) {
         case VARIANT_PAPER: return launch_linearize_t<DimsPaper>(cfg, d_in, batch, A, Bj, Bt, c, stream);
+        case VARIANT_H2X: return launch_linearize_t<DimsH2x>(cfg, d_in, batch, A, Bj, Bt, c, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -7,15 +7,16 @@
 
 namespace vsmpc {
 
-enum Variant { VARIANT_NONE = 0, VARIANT_PAPER = 1 };
+enum Variant { VARIANT_NONE = 0, VARIANT_PAPER = 1, VARIANT_H2X = 2 };
 
 int select_variant(int n_iter, int n_iter_small, int control_horizon);
 const char* variant_kernel_name(int variant);
 int variant_condensed_dim(int variant);
+size_t variant_workspace_doubles(int variant);  // per-instance global workspace of the factor (0 = lives in LDS)
 
 hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                         int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
-                        hipStream_t stream);
+                        double* ws, hipStream_t stream);
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                             double* Bt, double* c, hipStream_t stream);
 

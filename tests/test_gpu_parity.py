@@ -294,3 +294,67 @@ def test_kinematics_terms_match_oracle(mpc, ref, synth, layout):
     # the patched records still solve (I_G symmetric positive definite here)
     x, fm, st, it = mpc.solve(recs)
     assert (st == layout.STATUS_SOLVED).all()
+
+
+@pytest.fixture(scope="module")
+def mpc2x(solver_mod, layout):
+    m = solver_mod.BatchedVSMPC(layout.horizon2x_config(), device=0, max_batch=256)
+    yield m
+    m.close()
+
+
+def test_horizon2x_golden_and_oracle(mpc2x, ref, synth, layout, golden_h2x):
+    """BASELINE.json configs[4]: 2x horizon at halved fast-rate dt (1146 variables, 994 rows, condensed dimension 236).
+    The factor lives in a global workspace for this variant; many throttle bounds are active."""
+    cfg, rcfg = layout.horizon2x_config(), ref.horizon2x_config()
+    assert mpc2x.n_var == 1146 and mpc2x.n_con == 994 and mpc2x.n_in == 414 and mpc2x.n_p == 240
+    x, fm, st, it = mpc2x.solve(golden_h2x["inputs"])
+    assert (st == layout.STATUS_SOLVED).all()
+    for b in range(len(x)):
+        assert relerr(x[b], golden_h2x["x"][b]) < TOL
+        assert relerr(fm[b], golden_h2x["first_move"][b]) < TOL
+    np.testing.assert_array_equal(it, golden_h2x["iters"])
+    recs = np.concatenate([synth.make_batch(cfg, 8, workload=w, first_index=30) for w in ("hover", "takeoff", "montecarlo")])
+    x, fm, st, it = mpc2x.solve(recs)
+    assert (st == layout.STATUS_SOLVED).all()
+    nact = 0
+    vmin, vmax = ref.throttle_bounds(rcfg)
+    for b, rec in enumerate(recs):
+        xr, yr, itr, _ = ref.solve_instance(rcfg, rec)
+        assert relerr(x[b], xr) < TOL and it[b] == itr
+        assert relerr(fm[b], ref.first_move_vector(rcfg, xr)) < TOL
+        v = xr[rcfg.off_throttle:]
+        nact += int((np.abs(v - vmax) < 1e-12).sum() + (np.abs(v - vmin) < 1e-12).sum())
+    assert nact > 20 and it.max() >= 3
+
+
+def test_horizon2x_blocks_and_batch(mpc2x, ref, synth, layout):
+    cfg, rcfg = layout.horizon2x_config(), ref.horizon2x_config()
+    recs = synth.make_batch(cfg, 2, workload="hover")
+    A, Bj, Bt, c, dt = mpc2x.linearize(recs)
+    np.testing.assert_allclose(dt, ref.dt_schedule(rcfg), rtol=0, atol=1e-17)
+    Ar, Bjr, Btr, cr = ref.linearize(rcfg, recs[1])
+    assert relerr(A[1], Ar) < 1e-13 and relerr(c[1], cr) < 1e-13
+    M, Lf = mpc2x.debug_condensed(recs[1])
+    H, g, Ac, lo, hi = ref.assemble_dense(rcfg, recs[1])
+    nxs = 26 * 35
+    sol = np.linalg.solve(Ac[:nxs, :nxs], np.column_stack([lo[:nxs], Ac[:nxs, nxs:]]))
+    Z = np.vstack([-sol[:, 1:], np.eye(236)])
+    xp = np.concatenate([sol[:, 0], np.zeros(236)])
+    Hr, gr = Z.T @ H @ Z, Z.T @ (H @ xp + g)
+    perm = list(range(192)) + list(range(196, 236)) + list(range(192, 196))
+    Hr, gr = Hr[np.ix_(perm, perm)], gr[perm]
+    Mh = np.tril(M[:236, :236]); Mh = Mh + np.tril(Mh, -1).T
+    assert relerr(Mh, Hr) < 1e-11 and relerr(M[236, :236], gr) < 1e-11
+    Lr = np.linalg.cholesky(0.5 * (Hr + Hr.T))
+    assert relerr(np.tril(Lf[:236, :236]), Lr) < 1e-10
+    # a full 256-instance launch: determinism + feasibility properties
+    big = synth.make_batch(cfg, 64, workload="takeoff")
+    big = np.tile(big, (4, 1))
+    x, fm, st, it = mpc2x.solve(big)
+    assert (st == layout.STATUS_SOLVED).all()
+    for k in range(1, 4):
+        np.testing.assert_array_equal(x[:64], x[64 * k:64 * (k + 1)])
+    np.testing.assert_array_equal(x[:, 0:26], big[:, 0:26])
+    vmin, vmax = ref.throttle_bounds(rcfg)
+    assert x[:, rcfg.off_throttle:].min() >= vmin and x[:, rcfg.off_throttle:].max() <= vmax
