@@ -104,12 +104,14 @@ VS_DEV int lower_at(int gr, int gc) {
 // ------------------------------------------------------------------------------------------------
 // P0: linearisation into LDS (dense, row-major) — also the body of the linearise-only kernel
 // ------------------------------------------------------------------------------------------------
-template <class D>
+template <class D, bool ZERO = true>
 VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, double* __restrict__ sA,
                          double* __restrict__ sBj, double* __restrict__ sBt, double* __restrict__ sC,
                          double* __restrict__ sVprev, int tid, int nthreads) {
-    for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += nthreads) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
-    __syncthreads();
+    if constexpr (ZERO) {
+        for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += nthreads) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
+        __syncthreads();
+    }
     if (tid == 0) {
         // A[rpy, angMom] = W(rpy)^-1 * I_G^-1                       (systemDynamicsVSMPC.cpp:86-87,140-147)
         const double* I = sIn + VSMPC_IN_INERTIA;
@@ -121,7 +123,10 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
         const double Ii[9] = {A00 * idet, A01 * idet, A02 * idet, A10 * idet, A11 * idet,
                               A12 * idet, A20 * idet, A21 * idet, A22 * idet};
         const double r = sIn[VSMPC_IN_RPY + 0], p = sIn[VSMPC_IN_RPY + 1];
-        const double sr = sin(r), cr = cos(r), cp = cos(p), tp = tan(p);
+        double sr, cr, sp, cp;
+        sincos(r, &sr, &cr);
+        sincos(p, &sp, &cp);
+        const double tp = sp / cp;
         const double Wi[9] = {1.0, sr * tp, cr * tp, 0.0, cr, -sr, 0.0, sr / cp, cr / cp};
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
@@ -566,8 +571,9 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     }
     if (tid < 4) sFlags[tid] = 0;
     if (tid < D::N) sDt[tid] = cfg.dt[tid];
+    for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
     __syncthreads();
-    p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);
+    p0_linearize<D, false>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);
 
     VS_STAMP(1);
     // ---------------------------------------------------------------- P1 condense
@@ -968,32 +974,118 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         for (int c = 0; c < NTH; ++c) f += sBt[r * NTH + c] * sV[vq + c];
         sF[e] = f;
     }
-    if (wave == 0 && lane < NX) {
-        // sparse image of row `lane` of A (at most 7 structural non-zeros per row), 8 slots
-        int n = 0;
-        for (int c = 0; c < NX; ++c) {
-            const double v = sA[lane * NX + c];
-            if (v != 0.0 && n < 8) { sEllV[lane * 8 + n] = v; sEllC[lane * 8 + n] = c; ++n; }
-        }
-        for (; n < 8; ++n) { sEllV[lane * 8 + n] = 0.0; sEllC[lane * 8 + n] = 0; }
-    }
     __syncthreads();
     if (wave == 0) {
-        const int r = lane < NX ? lane : NX - 1;
-        double ev[8];
-        int ec[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ev[e] = sEllV[r * 8 + e]; ec[e] = sEllC[r * 8 + e]; }
-        double x = sIn[VSMPC_IN_X0 + r];
-        if (lane < NX) sX[lane] = x;
+        // The model is a cascade (systemDynamicsVSMPC.cpp:79-103,288-319,384-429): jets -> momenta -> CoM / RPY ->
+        // error integrators.  Each link is a short register recursion in a few lanes of ONE wavefront; links hand
+        // their trajectories over through sX (LDS operations of a wavefront execute in order).
+        // Every chain first pulls a chunk of CHK stages of its forcing terms into registers (the loads cannot be
+        // hoisted past the trajectory stores by the compiler), then runs the recursion on registers.
+        constexpr int CHK = 9;
+        // (1) jets: lane i < 4 carries (T_i, Tdot_i)
+        if (lane < NTH) {
+            const int i = lane;
+            const double jon = sA[(12 + i) * NX + 16 + i], ja = sA[(16 + i) * NX + 12 + i], jb = sA[(16 + i) * NX + 16 + i];
+            double T = sIn[VSMPC_IN_X0 + 12 + i], Td = sIn[VSMPC_IN_X0 + 16 + i];
+            sX[12 + i] = T;
+            sX[16 + i] = Td;
 #pragma unroll 1
-        for (int k = 0; k < D::N; ++k) {
-            const double* xk = sX + NX * k;  // written by this wavefront in the previous iteration (in-order LDS)
-            double d = sF[NX * k + r];
+            for (int k0 = 0; k0 < D::N; k0 += CHK) {
+                double fa[CHK], fb[CHK], dtk[CHK];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d += ev[e] * xk[ec[e]];
-            x += sDt[k] * d;
-            if (lane < NX) sX[NX * (k + 1) + lane] = x;
+                for (int u = 0; u < CHK; ++u) {
+                    const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+                    fa[u] = sF[NX * k + 12 + i];
+                    fb[u] = sF[NX * k + 16 + i];
+                    dtk[u] = sDt[k];
+                }
+#pragma unroll
+                for (int u = 0; u < CHK; ++u) {
+                    const double dT = fma(jon, Td, fa[u]);
+                    const double dTd = fma(ja, T, fma(jb, Td, fb[u]));
+                    T = fma(dtk[u], dT, T);
+                    Td = fma(dtk[u], dTd, Td);
+                    if (k0 + u < D::N) {
+                        sX[NX * (k0 + u + 1) + 12 + i] = T;
+                        sX[NX * (k0 + u + 1) + 16 + i] = Td;
+                    }
+                }
+            }
+        }
+        // (2) momentum forcing g_k = A_mom T_k + f_k on the six momentum rows, all stages at once (into sF)
+        for (int e = lane; e < 6 * D::N; e += 64) {
+            const int k = e / 6, rr = e - 6 * k, row = rr < 3 ? 3 + rr : 6 + rr;  // rows 3..5, 9..11
+            double gk = sF[NX * k + row];
+#pragma unroll
+            for (int c = 0; c < NTH; ++c) gk = fma(sA[row * NX + 12 + c], sX[NX * k + 12 + c], gk);
+            sF[NX * k + row] = gk;
+        }
+        // (3) momenta: lane g < 2 carries h_lin (g = 0) or h_ang (g = 1), h' = -S(omega) h + g_k
+        if (lane < 2) {
+            const int hr0 = lane ? 9 : 3;
+            double Sk[9], h[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                h[r] = sIn[VSMPC_IN_X0 + hr0 + r];
+                sX[hr0 + r] = h[r];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < D::N; k0 += CHK) {
+                double gk[CHK][3], dtk[CHK];
+#pragma unroll
+                for (int u = 0; u < CHK; ++u) {
+                    const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) gk[u][r] = sF[NX * k + hr0 + r];
+                    dtk[u] = sDt[k];
+                }
+#pragma unroll
+                for (int u = 0; u < CHK; ++u) {
+                    double dh[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        dh[r] = fma(Sk[3 * r], h[0], fma(Sk[3 * r + 1], h[1], fma(Sk[3 * r + 2], h[2], gk[u][r])));
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) h[r] = fma(dtk[u], dh[r], h[r]);
+                    if (k0 + u < D::N) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) sX[NX * (k0 + u + 1) + hr0 + r] = h[r];
+                    }
+                }
+            }
+        }
+        // (4) CoM / RPY and their error integrators: lane (g, r) < 6, x' = M1 h, e' = x + c_e
+        if (lane < 6) {
+            const int g = lane / 3, r = lane - 3 * g;
+            const int xr = (g ? 6 : 0) + r, hr0 = g ? 9 : 3, er = (g ? 23 : 20) + r;
+            const double m0 = sA[xr * NX + hr0], m1 = sA[xr * NX + hr0 + 1], m2 = sA[xr * NX + hr0 + 2];
+            const double ce = sC[er];
+            double x = sIn[VSMPC_IN_X0 + xr], ee = sIn[VSMPC_IN_X0 + er];
+            sX[xr] = x;
+            sX[er] = ee;
+#pragma unroll 1
+            for (int k0 = 0; k0 < D::N; k0 += CHK) {
+                double hk[CHK][3], dtk[CHK];
+#pragma unroll
+                for (int u = 0; u < CHK; ++u) {
+                    const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) hk[u][c] = sX[NX * k + hr0 + c];
+                    dtk[u] = sDt[k];
+                }
+#pragma unroll
+                for (int u = 0; u < CHK; ++u) {
+                    const double dx = fma(m0, hk[u][0], fma(m1, hk[u][1], m2 * hk[u][2]));
+                    ee = fma(dtk[u], x + ce, ee);
+                    x = fma(dtk[u], dx, x);
+                    if (k0 + u < D::N) {
+                        sX[NX * (k0 + u + 1) + xr] = x;
+                        sX[NX * (k0 + u + 1) + er] = ee;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
