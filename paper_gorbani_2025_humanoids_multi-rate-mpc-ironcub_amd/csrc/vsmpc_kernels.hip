@@ -249,20 +249,20 @@ VS_DEV void syrk_pass(d4 (&acc)[TPW], const double* const (&pa)[TPW], const doub
     double av[2][NACT], bv[2][NACT];
 #pragma unroll
     for (int q = 0; q < NACT; ++q) { av[0][q] = a[q][0]; bv[0][q] = b[q][0]; }
+    // each MFMA (64 cycles in the matrix pipe) is followed by the two operand loads of the same slot for the
+    // NEXT k-step: the loads issue in the shadow of the MFMA, so the pipe never waits for the load-issue burst
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        if (ks + 1 < NKS) {
 #pragma unroll
-            for (int q = 0; q < NACT; ++q) {
+        for (int q = 0; q < NACT; ++q) {
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks & 1][q], bv[ks & 1][q], acc[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NKS) {
                 av[(ks + 1) & 1][q] = a[q][(ks + 1) * 4 * D::YS];
                 bv[(ks + 1) & 1][q] = b[q][(ks + 1) * 4 * D::YS];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the next step's loads ahead of this step's MFMA chain
-#pragma unroll
-        for (int q = 0; q < NACT; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks & 1][q], bv[ks & 1][q], acc[q], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
