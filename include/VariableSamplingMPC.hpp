@@ -159,6 +159,8 @@ public:
     double getNInputMPC() const { return m_nInput; }
     const std::vector<double>& getSolution() const { return m_QPSolution; }   // IMPCProblem::getSolution
     TickState& tickState() { return m_tick; }
+    const vsmpc_config& config() const { return m_cfg; }
+    int inputDoubles() const { return m_nIn; }
 
 private:
     static bool copy(const std::vector<double>& v, double* out, int size) {

@@ -46,5 +46,28 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_bindings(force: bool = False) -> str | None:
+    """pybind11 shim `bindingsMPC` (reference Python surface, MPCPyBindings.cpp:12-91); host-only g++ build that links
+    libvsmpc.so.  Returns the module path, or None when pybind11 is not available."""
+    try:
+        import pybind11
+    except ImportError:
+        return None
+    import sysconfig
+    src = os.path.join(CSRC, "bindings_mpc.cpp")
+    out = os.path.join(HERE, "bindingsMPC" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    deps = [src, os.path.join(HERE, "..", "include", "VariableSamplingMPC.hpp"), os.path.join(HERE, "..", "include", "vsmpc.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    build_library()
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", f"-I{pybind11.get_include()}",
+           f"-I{sysconfig.get_paths()['include']}", src, "-o", out, f"-L{HERE}", "-lvsmpc",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("bindingsMPC build failed:\n" + res.stdout + res.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
