@@ -96,7 +96,10 @@ def main():
     solver = importlib.import_module(PKG + ".solver")
     sharding = importlib.import_module(PKG + ".sharding")
     import __graft_entry__ as ge
-    ge.build()
+    if rank == 0:
+        ge.build()                 # no-op when the in-tree libraries are current; only one rank may (re)build
+    if world > 1:
+        dist.barrier()
 
     cfg = pkg.paper_config() if args.config == "paper" else pkg.horizon2x_config()
     B = args.batch

@@ -19,7 +19,7 @@ def test_build_and_exports(solver_mod, pkg):
     import importlib
     _lib = importlib.import_module(pkg.__name__ + "._lib")
     assert os.path.exists(_lib.LIB_PATH)
-    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    cdll = _lib.load()          # imports torch first so that the library binds to torch's HIP runtime
     declared = header_functions()
     assert len(declared) >= 14
     for name in declared:

@@ -26,6 +26,7 @@ def shim(solver_mod):
     if path is None:
         pytest.skip("pybind11 not available")
     sys.path.insert(0, os.path.dirname(path))
+    import torch  # noqa: F401  (first: libvsmpc.so must bind to the HIP runtime torch brings along, see _lib.py)
     return importlib.import_module("bindingsMPC")
 
 
