@@ -154,8 +154,9 @@ def main():
             rec = json.load(open(tpath)).get(f"{args.config}:{args.workload}:{B}")
             traffic = rec["bytes_per_launch"] if rec else None
         out = {
-            "metric": "MPC solves/sec (whole node), iRonCub paper horizon" if args.config == "paper"
-                      else "MPC solves/sec (whole node), 2x horizon",
+            # BASELINE.json's metric; `value` is the solves/s part, the p50 latency part is `latency_single_solve_us`
+            "metric": "MPC solves/sec (whole node) + p50 single-solve latency, iRonCub paper horizon"
+                      if args.config == "paper" else "MPC solves/sec (whole node) + p50 single-solve latency, 2x horizon",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
