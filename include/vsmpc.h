@@ -184,6 +184,64 @@ int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsig
 int vsmpc_timing_begin(vsmpc_handle* h, void* stream);
 int vsmpc_timing_end(vsmpc_handle* h, void* stream, int launches, float* ms_per_launch);
 
+/*
+ * ---- Closed-loop batched rollout --------------------------------------------------------------
+ * The per-tick "advance" the reference hides inside its plugins and harness, for `batch` instances resident in HBM:
+ *   build record (tick state machine: 20-tick hold constraintsVSMPC.cpp:351-372, reference window costsVSMPC.cpp:
+ *   124-165, alpha cursor systemDynamicsVSMPC.cpp:308-311)  ->  solve  ->  apply the first move only if Solved
+ *   (variableSamplingMPC.cpp:91-108)  ->  integrate a centroidal + jet plant over periodMPC in 1 ms sub-steps
+ *   (the harness steps its simulator 5 x 1 ms per tick, ironcub_mujoco_simulator.py:122-139).
+ * The plant is a synthetic stand-in for MuJoCo (out of scope): the centroidal-momentum model the MPC linearises with
+ * the non-linear rotation kinematics and the non-linear jet polynomial (utils/src/JetModel.cpp:29-64).
+ *
+ * Plant state per instance, VSMPC_PLANT_STATE doubles: */
+#define VSMPC_PS_P 0        /* 3 CoM position                                   */
+#define VSMPC_PS_HLIN 3     /* 3 linear momentum, body frame                    */
+#define VSMPC_PS_RPY 6      /* 3 base roll/pitch/yaw                            */
+#define VSMPC_PS_HANG 9     /* 3 angular momentum, body frame                   */
+#define VSMPC_PS_T 12       /* 4 jet thrusts                                    */
+#define VSMPC_PS_TD 16      /* 4 jet thrust rates                               */
+#define VSMPC_PS_Q 20       /* 8 controlled joint positions                     */
+#define VSMPC_PS_U 28       /* 4 throttle command in percent (held between MPC moves) */
+#define VSMPC_PS_TDES 32    /* 4 last MPC thrust reference   (QPInput::getThrustDesMPC)    */
+#define VSMPC_PS_TDDES 36   /* 4 last MPC thrust-rate reference                            */
+#define VSMPC_PLANT_STATE 40
+/* Plant parameters per instance (constant over a rollout), VSMPC_PLANT_PARAMS doubles: */
+#define VSMPC_PP_MASS 0
+#define VSMPC_PP_INERTIA_B 1   /*   9 body-frame locked inertia, row-major                                          */
+#define VSMPC_PP_AMOM0 10      /*  24 A_mom(q_ref0) 6x4 row-major, body frame                                      */
+#define VSMPC_PP_DJ 34         /* 192 dA_mom/dq_j, [8][6][4]: A_mom(q) = A_mom0 + sum_j DJ[j] (q_j - q_ref0_j);
+                                      Lambda_lin/ang column j = DJ[j] T (systemDynamicsVSMPC.cpp:159-206,321-350)   */
+#define VSMPC_PP_QREF0 226     /*   8 posture reference q_ref0 (costsVSMPC.cpp:574-589)                             */
+#define VSMPC_PP_PINIT 234     /*   3 configure-time CoM position (costsVSMPC.cpp:105)                              */
+#define VSMPC_PP_RPYINIT 237   /*   3 configure-time RPY                                                            */
+#define VSMPC_PP_DIST_F 240    /*   3 disturbance force, world frame [N]                                            */
+#define VSMPC_PP_DIST_TAU 243  /*   3 disturbance torque, body frame [Nm]                                           */
+#define VSMPC_PP_DIST_T0 246   /*   disturbance active for DIST_T0 <= t < DIST_T1 [s]                               */
+#define VSMPC_PP_DIST_T1 247
+#define VSMPC_PP_TICK0 248     /*   tick index of this instance at rollout start (phase of the hold / trajectory)   */
+#define VSMPC_PLANT_PARAMS 249
+/* Log row per tick and instance: p(3) rpy(3) T(4) throttle%(4) status iters */
+#define VSMPC_ROLLOUT_LOG 16
+
+typedef struct vsmpc_rollout vsmpc_rollout;
+
+/* Allocates the resident rollout state for `batch` <= vsmpc_max_batch(h) instances.  The trajectories are shared by
+ * all instances, as in the reference's TrajectoryManager (TrajectoryManager.cpp:23-39): CoM position OFFSETS and
+ * velocities sampled every periodMPCLargeSteps (`n_traj` samples, [n_traj][3]), alpha_gravity sampled every
+ * `alpha_dt` seconds (`n_alpha` samples, linearly up-sampled to the tick rate); both are clamped at their ends. */
+int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, const double* traj_vel, int n_traj,
+                         const double* traj_alpha, int n_alpha, double alpha_dt, vsmpc_rollout** out);
+void vsmpc_rollout_destroy(vsmpc_rollout* r);
+/* Host -> device: state[batch][VSMPC_PLANT_STATE], params[batch][VSMPC_PLANT_PARAMS]; resets the tick counters. */
+int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* params);
+/* Runs `ticks` closed-loop ticks on `stream`; log (host, may be NULL) receives [ticks][batch][VSMPC_ROLLOUT_LOG].
+ * Returns after the last tick has completed. */
+int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream);
+/* Device -> host copies of the current plant state / the records of the LAST tick ([batch][n_in], parity hook). */
+int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state);
+int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
+
 const char* vsmpc_strerror(int code);
 const char* vsmpc_kernel_name(const vsmpc_handle* h);
 

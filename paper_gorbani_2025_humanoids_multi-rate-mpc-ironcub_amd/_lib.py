@@ -16,6 +16,8 @@ EXPORTS = (
     "vsmpc_max_batch", "vsmpc_solve_batch", "vsmpc_solve_batch_device", "vsmpc_linearize_batch",
     "vsmpc_assemble_dense", "vsmpc_condensed_dim", "vsmpc_debug_condensed", "vsmpc_timing_begin",
     "vsmpc_timing_end", "vsmpc_strerror", "vsmpc_kernel_name", "vsmpc_debug_phase_cycles", "vsmpc_kinematics_batch",
+    "vsmpc_rollout_create", "vsmpc_rollout_destroy", "vsmpc_rollout_reset", "vsmpc_rollout_run",
+    "vsmpc_rollout_get_state", "vsmpc_rollout_get_records",
 )
 
 _lib = None
@@ -65,6 +67,18 @@ def load():
     lib.vsmpc_timing_begin.restype = c_int
     lib.vsmpc_timing_end.argtypes = [vp, vp, c_int, ctypes.POINTER(ctypes.c_float)]
     lib.vsmpc_timing_end.restype = c_int
+    lib.vsmpc_rollout_create.argtypes = [vp, c_int, dp, dp, c_int, dp, c_int, ctypes.c_double, ctypes.POINTER(vp)]
+    lib.vsmpc_rollout_create.restype = c_int
+    lib.vsmpc_rollout_destroy.argtypes = [vp]
+    lib.vsmpc_rollout_destroy.restype = None
+    lib.vsmpc_rollout_reset.argtypes = [vp, dp, dp]
+    lib.vsmpc_rollout_reset.restype = c_int
+    lib.vsmpc_rollout_run.argtypes = [vp, c_int, dp, vp]
+    lib.vsmpc_rollout_run.restype = c_int
+    lib.vsmpc_rollout_get_state.argtypes = [vp, dp]
+    lib.vsmpc_rollout_get_state.restype = c_int
+    lib.vsmpc_rollout_get_records.argtypes = [vp, dp]
+    lib.vsmpc_rollout_get_records.restype = c_int
     lib.vsmpc_strerror.argtypes = [c_int]
     lib.vsmpc_strerror.restype = ctypes.c_char_p
     lib.vsmpc_kernel_name.argtypes = [vp]

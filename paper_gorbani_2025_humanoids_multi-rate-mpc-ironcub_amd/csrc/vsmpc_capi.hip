@@ -1,5 +1,6 @@
 // C-ABI of include/vsmpc.h: handle management, host<->device staging, dense-QP debug assembly.
 // No compute fallback lives here: every numeric result comes from the HIP kernels.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -27,6 +28,22 @@ struct vsmpc_handle {
     double* d_dbg;  // M | L for one instance
     double* d_ws;   // factor workspace for horizons whose factor does not fit LDS (max_batch instances)
     hipEvent_t ev0, ev1;
+};
+
+// resident closed-loop state of a batch (uses the handle's record / first-move / status buffers as its per-tick scratch)
+struct vsmpc_rollout {
+    vsmpc_handle* h;
+    int batch;
+    int substeps;
+    RolloutDev rd;
+    double* d_state;
+    double* d_params;
+    int* d_tick;
+    double* d_tpos;
+    double* d_tvel;
+    double* d_talpha;
+    double* d_log;
+    int log_ticks;
 };
 
 namespace {
@@ -380,6 +397,114 @@ int vsmpc_timing_end(vsmpc_handle* h, void* stream, int launches, float* ms_per_
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_per_launch = ms / float(launches);
+    return VSMPC_OK;
+}
+
+// ---- closed-loop rollout -------------------------------------------------------------------------------------
+
+int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, const double* traj_vel, int n_traj,
+                         const double* traj_alpha, int n_alpha, double alpha_dt, vsmpc_rollout** out) {
+    if (h == nullptr || out == nullptr || traj_pos == nullptr || traj_vel == nullptr || traj_alpha == nullptr ||
+        batch <= 0 || n_traj <= 0 || n_alpha <= 0 || !(alpha_dt > 0.0))
+        return VSMPC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
+    HIP_TRY(hipSetDevice(h->device));
+    vsmpc_rollout* r = new (std::nothrow) vsmpc_rollout();
+    if (r == nullptr) return VSMPC_ERR_ALLOC;
+    memset(r, 0, sizeof(*r));
+    r->h = h;
+    r->batch = batch;
+    r->rd.n_in = h->n_in;
+    r->rd.n_ref = h->cfg.n_iter - h->cfg.n_iter_small + 1;
+    r->rd.ratio = int(std::lround(h->cfg.period_large / h->cfg.period_small));   // constraintsVSMPC.cpp:322
+    r->rd.n_traj = n_traj;
+    r->rd.n_alpha = n_alpha;
+    r->rd.period_mpc = h->cfg.period_mpc;
+    r->rd.alpha_dt = alpha_dt;
+    r->substeps = std::max(1, int(std::lround(h->cfg.period_mpc / 1e-3)));      // 1 kHz plant, as the MuJoCo harness
+    const size_t B = size_t(batch);
+    hipError_t e = hipMalloc(&r->d_state, B * VSMPC_PLANT_STATE * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&r->d_params, B * VSMPC_PLANT_PARAMS * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&r->d_tick, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&r->d_tpos, size_t(n_traj) * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&r->d_tvel, size_t(n_traj) * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&r->d_talpha, size_t(n_alpha) * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(r->d_tpos, traj_pos, size_t(n_traj) * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_tvel, traj_vel, size_t(n_traj) * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(r->d_talpha, traj_alpha, size_t(n_alpha) * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(r->d_tick, 0, B * sizeof(int));
+    if (e != hipSuccess) {
+        vsmpc_rollout_destroy(r);
+        return e == hipErrorOutOfMemory ? VSMPC_ERR_ALLOC : hip_fail(e, "vsmpc_rollout_create");
+    }
+    *out = r;
+    return VSMPC_OK;
+}
+
+void vsmpc_rollout_destroy(vsmpc_rollout* r) {
+    if (r == nullptr) return;
+    (void)hipSetDevice(r->h->device);
+    if (r->d_state) (void)hipFree(r->d_state);
+    if (r->d_params) (void)hipFree(r->d_params);
+    if (r->d_tick) (void)hipFree(r->d_tick);
+    if (r->d_tpos) (void)hipFree(r->d_tpos);
+    if (r->d_tvel) (void)hipFree(r->d_tvel);
+    if (r->d_talpha) (void)hipFree(r->d_talpha);
+    if (r->d_log) (void)hipFree(r->d_log);
+    delete r;
+}
+
+int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* params) {
+    if (r == nullptr || state == nullptr || params == nullptr) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(r->h->device));
+    const size_t B = size_t(r->batch);
+    HIP_TRY(hipMemcpy(r->d_state, state, B * VSMPC_PLANT_STATE * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->d_params, params, B * VSMPC_PLANT_PARAMS * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(r->d_tick, 0, B * sizeof(int)));
+    return VSMPC_OK;
+}
+
+int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
+    if (r == nullptr || ticks < 0) return VSMPC_ERR_INVALID_ARG;
+    if (ticks == 0) return VSMPC_OK;
+    vsmpc_handle* h = r->h;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t row = size_t(r->batch) * VSMPC_ROLLOUT_LOG;
+    if (log != nullptr && r->log_ticks < ticks) {
+        if (r->d_log) (void)hipFree(r->d_log);
+        r->d_log = nullptr;
+        r->log_ticks = 0;
+        hipError_t e = hipMalloc(&r->d_log, size_t(ticks) * row * sizeof(double));
+        if (e != hipSuccess) return e == hipErrorOutOfMemory ? VSMPC_ERR_ALLOC : hip_fail(e, "vsmpc_rollout_run");
+        r->log_ticks = ticks;
+    }
+    // three launches per tick, all on `s`: the stream order is the only synchronisation the loop needs
+    for (int t = 0; t < ticks; ++t) {
+        HIP_TRY(launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha,
+                              h->d_in, s));
+        HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+                             nullptr, nullptr, h->d_ws, s));
+        HIP_TRY(launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
+                               r->d_talpha, log ? r->d_log + size_t(t) * row : nullptr, r->substeps, s));
+    }
+    if (log) HIP_TRY(hipMemcpyAsync(log, r->d_log, size_t(ticks) * row * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VSMPC_OK;
+}
+
+int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state) {
+    if (r == nullptr || state == nullptr) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(r->h->device));
+    HIP_TRY(hipMemcpy(state, r->d_state, size_t(r->batch) * VSMPC_PLANT_STATE * sizeof(double), hipMemcpyDeviceToHost));
+    return VSMPC_OK;
+}
+
+int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records) {
+    if (r == nullptr || records == nullptr) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(r->h->device));
+    HIP_TRY(hipMemcpy(records, r->h->d_in, size_t(r->batch) * r->h->n_in * sizeof(double), hipMemcpyDeviceToHost));
     return VSMPC_OK;
 }
 

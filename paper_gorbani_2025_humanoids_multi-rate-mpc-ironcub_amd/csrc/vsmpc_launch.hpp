@@ -22,4 +22,16 @@ hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, 
 
 hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipStream_t stream);
 
+// closed-loop rollout (vsmpc_rollout.hip)
+struct RolloutDev {
+    int n_in, n_ref, ratio, n_traj, n_alpha;
+    double period_mpc, alpha_dt;
+};
+hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,
+                         const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* rec,
+                         hipStream_t stream);
+hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
+                          const int* status, const int* iters, const double* traj_alpha, double* log_row, int substeps,
+                          hipStream_t stream);
+
 }  // namespace vsmpc

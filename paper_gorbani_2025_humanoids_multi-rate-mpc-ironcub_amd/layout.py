@@ -58,6 +58,14 @@ FM_THRUST = 16
 FM_THRUSTDOT = 20
 FM_SIZE = 24
 
+# closed-loop rollout: plant state / parameter layouts (VSMPC_PS_* / VSMPC_PP_* in include/vsmpc.h)
+PS_P, PS_HLIN, PS_RPY, PS_HANG, PS_T, PS_TD, PS_Q, PS_U, PS_TDES, PS_TDDES = 0, 3, 6, 9, 12, 16, 20, 28, 32, 36
+PLANT_STATE = 40
+PP_MASS, PP_INERTIA_B, PP_AMOM0, PP_DJ, PP_QREF0, PP_PINIT, PP_RPYINIT = 0, 1, 10, 34, 226, 234, 237
+PP_DIST_F, PP_DIST_TAU, PP_DIST_T0, PP_DIST_T1, PP_TICK0 = 240, 243, 246, 247, 248
+PLANT_PARAMS = 249
+ROLLOUT_LOG = 16
+
 # per-instance status (mirrors the OsqpEigen::Status values the reference distinguishes,
 # IMPCProblem.cpp:285-294, variableSamplingMPC.cpp:91)
 STATUS_SOLVED = 1

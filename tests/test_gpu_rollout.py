@@ -1,0 +1,113 @@
+"""GPU tests of the closed-loop rollout: record builder and plant advance kernels against their
+numpy model, a short closed loop against the oracle-in-the-loop model, and closed-loop properties at batch scale."""
+import importlib
+
+import numpy as np
+import pytest
+
+import rollout_model as rm
+from conftest import PKG, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ro(solver_mod):
+    return importlib.import_module(PKG + ".rollout")
+
+
+def _make(ro, layout, batch, workload, horizon_s=60.0):
+    cfg = layout.paper_config()
+    st, pa = ro.make_plant(cfg, batch, workload=workload)
+    pos, vel, alpha, adt = ro.make_trajectory(cfg, "takeoff" if workload == "takeoff" else "hover", horizon_s)
+    r = ro.ClosedLoopRollout(cfg, batch, pos, vel, alpha, adt, device=0)
+    r.reset(st, pa)
+    return cfg, st, pa, (pos, vel, alpha, adt), r
+
+
+@pytest.mark.parametrize("workload", ["hover", "takeoff", "montecarlo"])
+def test_record_and_advance_kernels_match_model(ro, layout, workload):
+    B = 12
+    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, workload)
+    try:
+        s_host = st.copy()
+        for tick in range(3):
+            log = r.run(1)
+            recs = r.last_records()
+            fm, status = None, None
+            x, fm, status, iters = r.mpc.solve(recs)          # same kernel, same records -> the first move the loop used
+            after = r.state()
+            for b in range(B):
+                rec_m = rm.build_record(cfg, s_host[b], pa[b], tick, pos, vel, alpha, adt)
+                assert relerr(recs[b], rec_m) < 1e-13, (workload, tick, b)
+                s_m = rm.advance(cfg, s_host[b], pa[b], tick, fm[b], status[b], alpha, adt)
+                assert relerr(after[b], s_m) < 1e-12, (workload, tick, b)
+                assert log[0, b, 14] == status[b] and log[0, b, 15] == iters[b]
+                np.testing.assert_allclose(log[0, b, 0:3], after[b, 0:3], rtol=0, atol=0)
+            s_host = after
+    finally:
+        r.close()
+
+
+def test_closed_loop_matches_oracle_in_the_loop(ro, layout, ref):
+    """45 ticks (two releases of the 20-tick hold) of 2 hover instances: the resident GPU loop against the numpy
+    model driven by the oracle's exact QP optimum, state by state."""
+    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, 2, "hover")
+    rcfg = ref.paper_config()
+    try:
+        r.run(45, log=False)
+        gpu = r.state()
+    finally:
+        r.close()
+    for b in range(2):
+        s = st[b].copy()
+        for tick in range(45):
+            rec = rm.build_record(cfg, s, pa[b], tick, pos, vel, alpha, adt)
+            x, _, _, _ = ref.solve_instance(rcfg, rec)
+            s = rm.advance(cfg, s, pa[b], tick, ref.first_move_vector(rcfg, x), 1, alpha, adt)
+        assert relerr(gpu[b], s) < 1e-8, b
+
+
+def test_hover_rollout_properties(ro, layout):
+    """64 instances x 800 ticks (4 s): every solve optimal, throttle moves only on the free tick of the hold, the
+    flight stays near the reference and the attitude converges."""
+    B, T = 64, 800
+    cfg, st, pa, _, r = _make(ro, layout, B, "hover")
+    try:
+        log = r.run(T)
+        final = r.state()
+    finally:
+        r.close()
+    assert (log[:, :, 14] == 1).all()
+    u = log[:, :, 10:14]
+    tick0 = pa[:, layout.PP_TICK0].astype(int)
+    changed = np.abs(np.diff(u, axis=0)).max(axis=2) > 1e-9                   # [T-1, B]: command differs from previous tick
+    phase = (np.arange(1, T)[:, None] + tick0[None, :]) % cfg.ratio
+    assert changed.any() and (phase[changed] == cfg.ratio - 1).all()
+    p_err = np.abs(log[:, :, 0:3] - pa[None, :, layout.PP_PINIT:layout.PP_PINIT + 3])
+    assert p_err.max() < 0.6
+    rpy_err0 = np.abs(st[:, layout.PS_RPY:layout.PS_RPY + 3] - pa[:, layout.PP_RPYINIT:layout.PP_RPYINIT + 3]).max(axis=1)
+    rpy_errT = np.abs(log[-200:, :, 3:6] - pa[None, :, layout.PP_RPYINIT:layout.PP_RPYINIT + 3]).max(axis=(0, 2))
+    assert np.median(rpy_errT) < 0.8 * np.median(rpy_err0) and rpy_errT.max() < 0.15   # lightly damped, see DESIGN.md
+    assert np.isfinite(final).all()
+    assert (final[:, layout.PS_T:layout.PS_T + 4] > 50).all() and (final[:, layout.PS_T:layout.PS_T + 4] < 260).all()
+
+
+@pytest.mark.parametrize("workload", ["takeoff", "montecarlo"])
+def test_disturbed_and_takeoff_rollouts_stay_bounded(ro, layout, workload):
+    B, T = 64, 400
+    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, workload)
+    try:
+        log = r.run(T)
+        final = r.state()
+    finally:
+        r.close()
+    assert np.isfinite(log).all() and np.isfinite(final).all()
+    solved = (log[:, :, 14] == 1).mean()
+    assert solved > 0.999, solved
+    assert np.abs(log[:, :, 3:6]).max() < 0.6                                  # attitude stays small
+    # altitude follows the moving reference within 0.6 m
+    tick_end = pa[:, layout.PP_TICK0].astype(int) + T
+    idx = np.minimum(tick_end // cfg.ratio, len(pos) - 1)
+    z_ref = pa[:, layout.PP_PINIT + 2] + pos[idx, 2]
+    assert np.abs(final[:, layout.PS_P + 2] - z_ref).max() < 0.6
