@@ -84,8 +84,8 @@ void fill_devcfg(const vsmpc_config& c, DevCfg& d) {
     d.w_reg = c.w_reg_joint_pos;
     d.w_thr = c.w_throttle;
     d.w_init = c.w_initial_throttle;
-    d.vmin = Jet::v_of_throttle(c.throttle_min);  // constraintsVSMPC.cpp:329-332
-    d.vmax = Jet::v_of_throttle(c.throttle_max);
+    d.vmin = Jet::v_of_throttle_div(c.throttle_min);  // constraintsVSMPC.cpp:329-332
+    d.vmax = Jet::v_of_throttle_div(c.throttle_max);
     d.use_jet = c.use_jet_dynamic ? 1 : 0;
     d.max_as_iter = 64;
 }
@@ -279,7 +279,7 @@ int vsmpc_assemble_dense(vsmpc_handle* h, const double* in_one, double* H, doubl
     // ThrottleInitialValueCost (costsVSMPC.cpp:468-487)
     double vprev[NTH];
     for (int r = 0; r < NTH; ++r) {
-        vprev[r] = Jet::v_of_throttle(in_one[VSMPC_IN_UPREV + r]);
+        vprev[r] = Jet::v_of_throttle_div(in_one[VSMPC_IN_UPREV + r]);
         Hat(offV + r, offV + r) += cf.w_initial_throttle;
         g[offV + r] += -cf.w_initial_throttle * vprev[r];
     }

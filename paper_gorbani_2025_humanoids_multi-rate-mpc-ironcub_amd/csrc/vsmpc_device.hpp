@@ -84,10 +84,15 @@ struct Jet {
     static VS_HD double dg_dT(double T, double Td) { return c7 + c9 * Td + 2 * c10 * T; }
     static VS_HD double dg_dTd(double T, double Td) { return c8 + c9 * T + 2 * c11 * Td; }
     static VS_HD double v(double u) { return u + c12 * u * u; }
-    static VS_HD double stdT(double T) { return (T - muT) / sgT; }
-    static VS_HD double stdTd(double Td) { return Td / sgT; }
-    static VS_HD double stdU(double u) { return (u - muU) / sgU; }
+    // reciprocals as constants: an FP64 division costs ~40 instructions on the device
+    static constexpr double isgT = 1.0 / sgT, isgU = 1.0 / sgU;
+    static VS_HD double stdT(double T) { return (T - muT) * isgT; }
+    static VS_HD double stdTd(double Td) { return Td * isgT; }
+    static VS_HD double stdU(double u) { return (u - muU) * isgU; }
     static VS_HD double v_of_throttle(double u_percent) { return v(stdU(u_percent)); }
+    // values that are compared with each other exactly (v_min, v_max, the pinned previous throttle) use the reference's
+    // division (JetModel.cpp:80-83) so that they round identically to it
+    static VS_HD double v_of_throttle_div(double u_percent) { return v((u_percent - muU) / sgU); }
     // JetModel::destandardizeThrottle_u2T (JetModel.cpp:93-109)
     static VS_HD double throttle_of_v(double vv) {
         double u = (-1.0 + sqrt(1.0 + 4.0 * c12 * vv)) / (2.0 * c12);

@@ -44,7 +44,10 @@ VS_DEV double readlane_f64(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(d) and 1/d: hardware seed + Newton steps (full double precision to ~2 ulp)
+// 1/sqrt(d) and 1/d: hardware seed + refinement (full double precision to ~2 ulp)
+// The v_rsq_f64 / v_rcp_f64 seeds are good to 5e-8 (profiles/r01_microbench_rsq_accuracy.txt): two Newton steps
+// give full precision (2.4e-16), one leaves 4e-15.  A single cubically convergent (Halley) step is just as accurate
+// with a shorter dependent chain, but measured 3 k cycles SLOWER over the 120 Cholesky pivots (worse schedule).
 VS_DEV double fast_rsqrt(double d) {
     double y = __builtin_amdgcn_rsq(d);
     const double h = 0.5 * d;
@@ -88,8 +91,18 @@ struct Smem {
     static constexpr int sizeY = NYBUF * YROWS * D::YS;
     static constexpr int oM = oY;                    // the factor's tiles reuse the Y buffers (dead after P1)
     static constexpr int sizeM = D::L_IN_LDS ? D::NTRI * D::TS : 0;
-    static constexpr int total = oY + (sizeY > sizeM ? sizeY : sizeM);
+    // P5 without a serial chain (paper horizon, where LDS has the room): X_p = L_pp^-1 of the joint diagonal tiles and
+    // G_pq = X_p L_pq of the joint tiles below them, both produced by the wavefronts that idle during the panel
+    // factorisations of P3
+    static constexpr bool FASTSWEEP = D::L_IN_LDS;
+    static constexpr int NJT = D::NU >> 4;           // joint tile rows
+    static constexpr int oXinv = oY + (sizeY > sizeM ? sizeY : sizeM);
+    static constexpr int sizeXinv = FASTSWEEP ? NJT * D::TS : 0;
+    static constexpr int oG = oXinv + sizeXinv;
+    static constexpr int sizeG = FASTSWEEP ? (NJT * (NJT - 1) / 2) * D::TS : 0;
+    static constexpr int total = oG + sizeG;
     static constexpr size_t bytes = size_t(total) * sizeof(double);
+    static_assert(bytes <= 160 * 1024, "LDS budget of one CU");
 };
 
 template <class D>
@@ -112,6 +125,8 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
         for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += nthreads) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
         __syncthreads();
     }
+    // The independent pieces run in different wavefronts (0: attitude kinematics, 1: jets, 2: CoM / gravity, 2-3: copies)
+    // so that their divergent paths overlap instead of serialising inside one wavefront; needs >= 256 threads.
     if (tid == 0) {
         // A[rpy, angMom] = W(rpy)^-1 * I_G^-1                       (systemDynamicsVSMPC.cpp:86-87,140-147)
         const double* I = sIn + VSMPC_IN_INERTIA;
@@ -119,25 +134,25 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
         const double A00 = e * k - f * h, A01 = c * h - b * k, A02 = b * f - c * e;
         const double A10 = f * g - d * k, A11 = a * k - c * g, A12 = c * d - a * f;
         const double A20 = d * h - e * g, A21 = b * g - a * h, A22 = a * e - b * d;
-        const double idet = 1.0 / (a * A00 + b * A10 + c * A20);
+        const double idet = fast_rcp(a * A00 + b * A10 + c * A20);
         const double Ii[9] = {A00 * idet, A01 * idet, A02 * idet, A10 * idet, A11 * idet,
                               A12 * idet, A20 * idet, A21 * idet, A22 * idet};
         const double r = sIn[VSMPC_IN_RPY + 0], p = sIn[VSMPC_IN_RPY + 1];
         double sr, cr, sp, cp;
         sincos(r, &sr, &cr);
         sincos(p, &sp, &cp);
-        const double tp = sp / cp;
-        const double Wi[9] = {1.0, sr * tp, cr * tp, 0.0, cr, -sr, 0.0, sr / cp, cr / cp};
+        const double icp = fast_rcp(cp), tp = sp * icp;
+        const double Wi[9] = {1.0, sr * tp, cr * tp, 0.0, cr, -sr, 0.0, sr * icp, cr * icp};
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
                 double s = 0.0;
                 for (int q = 0; q < 3; ++q) s += Wi[3 * i + q] * Ii[3 * q + j];
                 sA[(6 + i) * NX + 9 + j] = s;
             }
-    } else if (tid >= 1 && tid <= 4) {
+    } else if (tid >= 64 && tid < 68) {
         // jets                                                      (systemDynamicsVSMPC.cpp:384-429)
-        const int i = tid - 1;
-        sVprev[i] = Jet::v_of_throttle(sIn[VSMPC_IN_UPREV + i]);
+        const int i = tid - 64;
+        sVprev[i] = Jet::v_of_throttle_div(sIn[VSMPC_IN_UPREV + i]);
         if (cfg.use_jet) {
             const double T0 = sIn[VSMPC_IN_T0 + i], Td0 = sIn[VSMPC_IN_TD0 + i], up = sIn[VSMPC_IN_UPREV + i];
             const double dhT = Jet::dh_dT(T0, Td0, up), dhTd = Jet::dh_dTd(T0, Td0, up);
@@ -149,9 +164,9 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
         } else {
             sBt[(12 + i) * NTH + i] = 1.0;
         }
-    } else if (tid == 5) {
+    } else if (tid == 128) {
         // CoM kinematics, -S(omega) blocks, gravity term, integrators  (systemDynamicsVSMPC.cpp:90-91,296-316)
-        const double m = sIn[VSMPC_IN_MASS], im = 1.0 / m;
+        const double m = sIn[VSMPC_IN_MASS], im = fast_rcp(m);
         const double* R = sIn + VSMPC_IN_WRB;
         const double* w = sIn + VSMPC_IN_OMEGA;
         const double* gr = sIn + VSMPC_IN_GRAV;
@@ -171,16 +186,16 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
             sC[20 + i] = -sIn[VSMPC_IN_PREF + i];
             sC[23 + i] = -sIn[VSMPC_IN_RPYINIT + i];
         }
-    } else if (tid >= 8 && tid < 32) {
+    } else if (tid >= 192 && tid < 216) {
         // thrust maps A[linMom|angMom, T] = A_mom,body                (systemDynamicsVSMPC.cpp:92-93,303-304)
-        const int e = tid - 8, r = e >> 2, j = e & 3;  // r in 0..5
+        const int e = tid - 192, r = e >> 2, j = e & 3;  // r in 0..5
         const int row = r < 3 ? 3 + r : 6 + r;         // 3..5, 9..11
         sA[row * NX + 12 + j] = sIn[VSMPC_IN_AMOM + e];
-    } else if (tid >= 32 && tid < 56) {
-        const int e = tid - 32, r = e >> 3, j = e & 7;  // Lambda_lin,B -> Bj[3..5]   (:305-306)
+    } else if (tid >= 216 && tid < 240) {
+        const int e = tid - 216, r = e >> 3, j = e & 7;  // Lambda_lin,B -> Bj[3..5]   (:305-306)
         sBj[(3 + r) * NJ + j] = sIn[VSMPC_IN_LLIN + e];
-    } else if (tid >= 56 && tid < 80) {
-        const int e = tid - 56, r = e >> 3, j = e & 7;  // Lambda_ang,B -> Bj[9..11]  (:94-95)
+    } else if (tid >= 136 && tid < 160) {
+        const int e = tid - 136, r = e >> 3, j = e & 7;  // Lambda_ang,B -> Bj[9..11]  (:94-95)
         sBj[(9 + r) * NJ + j] = sIn[VSMPC_IN_LANG + e];
     }
     __syncthreads();
@@ -190,24 +205,24 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
 // linearise-only kernel (vsmpc_linearize_batch)
 // ------------------------------------------------------------------------------------------------
 template <class D>
-__global__ __launch_bounds__(128) void linearize_kernel(DevCfg cfg, const double* __restrict__ in,
+__global__ __launch_bounds__(256) void linearize_kernel(DevCfg cfg, const double* __restrict__ in,
                                                          double* __restrict__ A, double* __restrict__ Bj,
                                                          double* __restrict__ Bt, double* __restrict__ c) {
     __shared__ double sIn[(D::NIN + 3) & ~3];
     __shared__ double sLin[NX * NX + NX * NJ + NX * NTH + 28 + 4];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int i = tid; i < D::NIN; i += 128) sIn[i] = in[size_t(b) * D::NIN + i];
+    for (int i = tid; i < D::NIN; i += 256) sIn[i] = in[size_t(b) * D::NIN + i];
     __syncthreads();
     double* sA = sLin;
     double* sBj = sA + NX * NX;
     double* sBt = sBj + NX * NJ;
     double* sC = sBt + NX * NTH;
     double* sVprev = sC + 28;
-    p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, 128);
-    for (int i = tid; i < NX * NX; i += 128) A[size_t(b) * NX * NX + i] = sA[i];
-    for (int i = tid; i < NX * NJ; i += 128) Bj[size_t(b) * NX * NJ + i] = sBj[i];
-    for (int i = tid; i < NX * NTH; i += 128) Bt[size_t(b) * NX * NTH + i] = sBt[i];
-    for (int i = tid; i < NX; i += 128) c[size_t(b) * NX + i] = sC[i];
+    p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, 256);
+    for (int i = tid; i < NX * NX; i += 256) A[size_t(b) * NX * NX + i] = sA[i];
+    for (int i = tid; i < NX * NJ; i += 256) Bj[size_t(b) * NX * NJ + i] = sBj[i];
+    for (int i = tid; i < NX * NTH; i += 256) Bt[size_t(b) * NX * NTH + i] = sBt[i];
+    for (int i = tid; i < NX; i += 256) c[size_t(b) * NX + i] = sC[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -392,11 +407,50 @@ VS_DEV void syrk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TP
 //       every wavefront updates the tiles it owns with four v_mfma_f64_16x16x4_f64 per tile.
 // All four instantiations execute the same number of workgroup barriers.
 // ------------------------------------------------------------------------------------------------
+// X = L_pp^-1 of one factored diagonal tile by one wavefront: lane j carries column j (lanes >= 16 shadow), the
+// entries of L_pp and 1/L_ii are wave-uniform LDS broadcasts.  X is stored like a tile: X[i][j] at i*17 + j.
+template <class D>
+VS_DEV void tile_inverse(const double* __restrict__ Lpp, const double* __restrict__ invd, double* __restrict__ X,
+                         int lane) {
+    const int j = lane & 15;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < i; k += 2) {
+            s0 = fma(Lpp[i * 17 + k], x[k], s0);
+            s1 = fma(Lpp[i * 17 + k + 1], x[k + 1], s1);
+        }
+        if (i & 1) s0 = fma(Lpp[i * 17 + i - 1], x[i - 1], s0);
+        const double di = invd[i];
+        x[i] = (i == j) ? di : -di * (s0 + s1);  // rows above the diagonal come out as (signed) zeros
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[i * 17 + j] = x[i];
+    }
+}
+
+// G = X L_pq (16x16x16 on the matrix core, four k-steps) for one tile below a joint diagonal tile
+VS_DEV void scaled_tile(const double* __restrict__ X, const double* __restrict__ Lpq, double* __restrict__ G, int crow,
+                        int lrow) {
+    double la[4], lb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { la[ks] = X[lrow + 4 * ks]; lb[ks] = Lpq[crow + 4 * ks * 17]; }
+    d4 g = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], lb[ks], g, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[crow + 4 * r * 17] = g[r];
+}
+
 template <class D, int TPW, int W>
 VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
-                          int lane, int crow, int lrow) {
+                          double* __restrict__ sXinv, double* __restrict__ sG, int lane, int crow, int lrow) {
     constexpr TileTab<D> tab{};
+    using S = Smem<D>;
     constexpr int PVT = D::NU >> 4;
     // ---- P2
 #pragma unroll
@@ -434,6 +488,19 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
                 bad = panel_factor_rt<D>(sM, sInvD, p, lane);
             }
             if (bad && lane == 0) sFlags[0] = 1;
+        }
+        if constexpr (S::FASTSWEEP) {
+            // the other wavefronts idle while wavefront 0 factors panel p: wavefront 1 inverts the diagonal tile
+            // finished one panel ago, wavefronts 2 and 3 scale the tiles left of the one finished two panels ago
+            if (W == 1 && p >= 1 && p - 1 < S::NJT)
+                tile_inverse<D>(sM + tile_off<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
+            if ((W == 2 || W == 3) && p >= 3 && p - 2 < S::NJT) {
+                const int pr = p - 2;
+#pragma unroll
+                for (int q = W - 2; q < pr; q += 2)
+                    scaled_tile(sXinv + pr * D::TS, sM + tile_off<D>(pr, q), sG + (pr * (pr - 1) / 2 + q) * D::TS, crow,
+                                lrow);
+            }
         }
         if constexpr (!D::L_IN_LDS) __threadfence_block();  // panel lives in global memory: order it for the other waves
         __syncthreads();
@@ -517,7 +584,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         }                                                                                   \
     } while (0)
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long t_mark = 0;
+    unsigned long long t_mark = 0, stamp_t1 = 0;
 #define VS_TIC()                                                     \
     do {                                                             \
         if constexpr (STAMPS) t_mark = __builtin_amdgcn_s_memtime(); \
@@ -552,6 +619,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     int* sEllC = reinterpret_cast<int*>(smem + S::oEllC);
     double* sY = smem + S::oY;
     double* sM = smem + S::oM;  // tile storage of the factor when it fits LDS
+    double* sXinv = smem + S::oXinv;  // inverses of the joint diagonal tiles, scaled joint tiles (see Smem)
+    double* sG = smem + S::oG;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -576,6 +645,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     p0_linearize<D, false>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);
 
     VS_STAMP(1);
+    if constexpr (STAMPS) stamp_t1 = __builtin_amdgcn_s_memtime();
     // ---------------------------------------------------------------- P1 condense
     // tiles of the lower triangle are dealt round-robin to the four wavefronts: tile t -> wave t%4, slot t/4
     constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
@@ -654,6 +724,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
 
         constexpr int NPASS = (D::N + 1) / 2;
         constexpr int BUFSZ = S::YROWS * D::YS;
+        if constexpr (STAMPS) { t_mark = stamp_t1; VS_TOC(3); }  // P1 set-up (coefficient and state loads)
 #pragma unroll 1
         for (int m = 0; m < NPASS; ++m) {
             const int bufoff = (S::NYBUF == 2) ? (m & 1) * BUFSZ : 0;
@@ -725,8 +796,10 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             // double-buffered Y: one barrier per pass (the next pass writes the other buffer); single buffer: two
             if constexpr (S::NYBUF == 1) __syncthreads();
         }
+        VS_TIC();
     }
     __syncthreads();
+    VS_TOC(4);  // waiting for the slowest wavefront of the last pass
     VS_STAMP(2);
 
     // ---------------------------------------------------------------- P2 + P3 (wave-specialised, see cholesky_wave)
@@ -760,17 +833,17 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     }
     VS_STAMP(3);
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-        case 3: cholesky_wave<D, TPW, 3>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
+        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
+        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
+        case 3: cholesky_wave<D, TPW, 3>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
         default:
             if constexpr (D::NWAVES > 4) {
                 switch (wave) {
-                    case 4: cholesky_wave<D, TPW, 4>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-                    case 5: cholesky_wave<D, TPW, 5>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-                    case 6: cholesky_wave<D, TPW, 6>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
-                    default: cholesky_wave<D, TPW, 7>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, lane, crow, lrow); break;
+                    case 4: cholesky_wave<D, TPW, 4>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
+                    case 5: cholesky_wave<D, TPW, 5>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
+                    case 6: cholesky_wave<D, TPW, 6>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
+                    default: cholesky_wave<D, TPW, 7>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
                 }
             }
             break;
@@ -950,11 +1023,43 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         __syncthreads();
         VS_STAMP(6);
 #pragma unroll 1
-        for (int p = D::NT - 1; p >= 0; --p) sweep_tile(p, true);
+        for (int p = D::NT - 1; p >= (S::FASTSWEEP ? PV : 0); --p) sweep_tile(p, true);
     } else {
         VS_STAMP(6);
+        if constexpr (!S::FASTSWEEP) {
 #pragma unroll 1
-        for (int p = PV - 1; p >= 0; --p) sweep_tile(p, false);
+            for (int p = PV - 1; p >= 0; --p) sweep_tile(p, false);
+        }
+    }
+    if constexpr (S::FASTSWEEP) {
+        // joint tiles: with G_pq = L_pp^-1 L_pq the right-hand sides of the tiles left of p are updated straight from
+        // w_p (no triangular solve on the chain): w_q -= G_pq^T w_p; afterwards every z_p = L_pp^-T w_p at once
+#pragma unroll
+        for (int p = PV - 1; p >= 1; --p) {
+            if (tid < 16 * p) {
+                const double* G = sG + (p * (p - 1) / 2 + (tid >> 4)) * D::TS + (tid & 15);
+                const double* wp = sW + 16 * p;
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    a0 = fma(G[k * 17], wp[k], a0);
+                    a1 = fma(G[(k + 1) * 17], wp[k + 1], a1);
+                }
+                sW[tid] -= a0 + a1;
+            }
+            __syncthreads();
+        }
+        if (tid < D::NU) {
+            const double* X = sXinv + (tid >> 4) * D::TS + (tid & 15);
+            const double* wp = sW + (tid & ~15);
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                z0 = fma(X[i * 17], wp[i], z0);
+                z1 = fma(X[(i + 1) * 17], wp[i + 1], z1);
+            }
+            sZ[tid] = z0 + z1;
+        }
     }
     if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
     __syncthreads();
@@ -1234,7 +1339,7 @@ static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batc
 template <class D>
 static hipError_t launch_linearize_t(const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                                      double* Bt, double* c, hipStream_t stream) {
-    hipLaunchKernelGGL(linearize_kernel<D>, dim3(batch), dim3(128), 0, stream, cfg, d_in, A, Bj, Bt, c);
+    hipLaunchKernelGGL(linearize_kernel<D>, dim3(batch), dim3(256), 0, stream, cfg, d_in, A, Bj, Bt, c);
     return hipGetLastError();
 }
 

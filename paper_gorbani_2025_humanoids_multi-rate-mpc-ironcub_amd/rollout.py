@@ -29,7 +29,8 @@ _JET = JetModel()
 def make_plant(cfg: L.MPCConfig, batch: int, *, workload: str = "hover", seed0: int = 4321, first_index: int = 0):
     """(state[batch, PLANT_STATE], params[batch, PLANT_PARAMS]) for `workload`:
     "hover"       start near the hover equilibrium (sigma as configs[1]), trajectory offsets zero
-    "takeoff"     start at rest at a random tick of the first 40 s of the take-off timeline (configs[2])
+    "takeoff"     start on the reference at a random tick of the flight part (19 s .. 35 s) of the take-off timeline
+                  (configs[2]); the plant has no ground contact, so the supported phase before lift-off is left out
     "montecarlo"  hover with 4x wider initial scatter and a disturbance push of up to 50 N / 30 Nm lasting 0.1 s
                   that starts within the first second (configs[3])
     Every instance is drawn from its own generator seeded seed0 + index, so any slice can be rebuilt on any rank."""
@@ -65,7 +66,7 @@ def make_plant(cfg: L.MPCConfig, batch: int, *, workload: str = "hover", seed0: 
         p_init = np.array([0.0, 0.0, 1.0])
         rpy_init = rng.normal(0.0, 0.01, size=3)
 
-        tick0 = int(rng.integers(0, 8001)) if workload == "takeoff" else int(rng.integers(0, cfg.ratio))
+        tick0 = int(rng.integers(3800, 7001)) if workload == "takeoff" else int(rng.integers(0, cfg.ratio))
         t0 = tick0 * cfg.period_mpc
         if workload == "takeoff":
             alpha = alpha_gravity_profile(t0)

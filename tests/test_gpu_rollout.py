@@ -93,21 +93,45 @@ def test_hover_rollout_properties(ro, layout):
     assert (final[:, layout.PS_T:layout.PS_T + 4] > 50).all() and (final[:, layout.PS_T:layout.PS_T + 4] < 260).all()
 
 
-@pytest.mark.parametrize("workload", ["takeoff", "montecarlo"])
-def test_disturbed_and_takeoff_rollouts_stay_bounded(ro, layout, workload):
-    B, T = 64, 400
-    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, workload)
+def _altitude_error(cfg, layout, log, pa, pos):
+    T = log.shape[0]
+    tick = pa[:, layout.PP_TICK0].astype(int)[None, :] + np.arange(1, T + 1)[:, None]
+    idx = np.minimum(tick // cfg.ratio, len(pos) - 1)
+    return np.abs(log[:, :, 2] - (pa[None, :, layout.PP_PINIT + 2] + pos[idx, 2]))
+
+
+def test_takeoff_rollout_tracks_the_moving_reference(ro, layout):
+    """64 loops started at random ticks of the climb (19 s .. 35 s of the take-off timeline), 4 s each: the altitude
+    follows the moving reference window, every solve is optimal."""
+    B, T = 64, 800
+    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, "takeoff")
+    try:
+        log = r.run(T)
+    finally:
+        r.close()
+    assert np.isfinite(log).all() and (log[:, :, 14] == 1).all()
+    ez = _altitude_error(cfg, layout, log, pa, pos)
+    assert ez.max() < 0.3, ez.max()
+    assert np.abs(log[:, :, 3:6]).max() < 0.15
+    climbing = pa[:, layout.PP_TICK0] < 6000                      # still on the ramp: the robot must actually climb
+    assert (log[-1, climbing, 2] > st[climbing, layout.PS_P + 2] + 0.05).all()
+
+
+def test_montecarlo_rollout_recovers_from_disturbances(ro, layout):
+    """configs[3]-style closed loops: 4x wider initial scatter (thrust imbalance up to ~20 %) and a 0.1 s push of up to
+    50 N / 30 Nm.  The jets are slow (seconds), so the excursion peaks after ~4 s; after 12 s the flight is back near
+    the reference.  Bounds are loose property checks on this synthetic plant, not reference numbers."""
+    B, T = 64, 2400
+    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, "montecarlo")
     try:
         log = r.run(T)
         final = r.state()
     finally:
         r.close()
     assert np.isfinite(log).all() and np.isfinite(final).all()
-    solved = (log[:, :, 14] == 1).mean()
-    assert solved > 0.999, solved
-    assert np.abs(log[:, :, 3:6]).max() < 0.6                                  # attitude stays small
-    # altitude follows the moving reference within 0.6 m
-    tick_end = pa[:, layout.PP_TICK0].astype(int) + T
-    idx = np.minimum(tick_end // cfg.ratio, len(pos) - 1)
-    z_ref = pa[:, layout.PP_PINIT + 2] + pos[idx, 2]
-    assert np.abs(final[:, layout.PS_P + 2] - z_ref).max() < 0.6
+    assert (log[:, :, 14] == 1).all()
+    assert log[:, :, 15].max() > 1                                  # some ticks needed real active-set iterations
+    ez = _altitude_error(cfg, layout, log, pa, pos)
+    assert ez.max() < 6.0 and np.abs(log[:, :, 3:6]).max() < 1.0   # bounded excursion
+    assert np.median(ez[-1]) < 0.25 and ez[-1].max() < 1.2         # recovered
+    assert np.median(ez[-1]) < 0.5 * np.median(ez[400])            # and much better than at the 2 s mark
