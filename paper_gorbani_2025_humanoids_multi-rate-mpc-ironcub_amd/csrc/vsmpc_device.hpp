@@ -39,7 +39,8 @@ struct Dims {
     static constexpr int NXS = NX * (N + 1);
     static constexpr int NVAR = NXS + NZ;
     static constexpr int NCON = NXS + NTH * (N - NS + 1);
-    static constexpr int YS = NP + 16;       // Y row stride (doubles): 16 mod 32 -> conflict-free b64 reads
+    // Y row stride (doubles), congruent 16 mod 32: the four row groups of a b64 operand read hit distinct banks
+    static constexpr int YS = ((NP + 16) % 32 == 16) ? NP + 16 : NP + 32;
     static constexpr int TS = 16 * 17;       // tile stride (16 rows, padded row stride 17)
     // workgroup shape: the sensitivity recursion runs one condensed column per thread and per half (linear /
     // angular), so the workgroup needs 2 * NP threads: 256 for the paper horizon, 512 for the 2x horizon

@@ -27,6 +27,8 @@
 // it (shared FP64 datapath); one FP64 FMA costs ~5.7 cycles for a lone wavefront, v_readlane pair + FMA
 // ~21.6.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
 // streams carry nothing but operand loads.
+#include <type_traits>
+
 #include "vsmpc_device.hpp"
 #include "vsmpc_launch.hpp"
 
@@ -346,48 +348,6 @@ __device__ __attribute__((noinline)) int panel_factor_rt(double* Lb, double* sIn
     return panel_factor<D, 1, 16>(Lb, sInvD, p, lane);
 }
 
-// Many tiles per wavefront (long horizons): the first NCH chunks of CH slots, branch-free; operands of the
-// next (k-step, chunk) are requested before the matrix-core chain of the current one.  Slots of an active chunk
-// that are not active yet multiply exact zeros.
-template <class D, int TPW, int CH, int NCH, int NKS>
-VS_DEV void syrk_chunks(d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW], int bufoff) {
-    double av[2][CH], bv[2][CH];
-    constexpr int NSTEP = NKS * NCH;
-#pragma unroll
-    for (int q = 0; q < CH; ++q) { av[0][q] = pa[q][bufoff]; bv[0][q] = pb[q][bufoff]; }
-#pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {
-        const int ks = st / NCH, ch = st % NCH;
-        if (st + 1 < NSTEP) {
-            const int ks1 = (st + 1) / NCH, ch1 = (st + 1) % NCH;
-#pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int qq = ch1 * CH + q;
-                if (qq < TPW) {
-                    av[(st + 1) & 1][q] = pa[qq][bufoff + ks1 * 4 * D::YS];
-                    bv[(st + 1) & 1][q] = pb[qq][bufoff + ks1 * 4 * D::YS];
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const int qq = ch * CH + q;
-            if (qq < TPW)
-                acc[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st & 1][q], bv[st & 1][q], acc[qq], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-template <class D, int TPW, int CH, int NKS, int NCH = (TPW + CH - 1) / CH>
-VS_DEV void syrk_chunk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TPW],
-                                const double* const (&pb)[TPW], int bufoff) {
-    if constexpr (NCH >= 1) {
-        if (nact > (NCH - 1) * CH) syrk_chunks<D, TPW, CH, NCH, NKS>(acc, pa, pb, bufoff);
-        else syrk_chunk_dispatch<D, TPW, CH, NKS, NCH - 1>(nact, acc, pa, pb, bufoff);
-    }
-}
-
 template <class D, int TPW, int NKS, int NACT = TPW>
 VS_DEV void syrk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW],
                           int bufoff) {
@@ -672,23 +632,46 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         else if (col < D::NZ) { kind = 1; blk = v_block_of_internal<D>(col - D::NU); comp = (col - D::NU) & 3; }
         else if (col == D::NZ) { kind = 2; }
 
+        // coefficient rows of this half.  Paper horizon: loaded once, they stay in registers for all passes.  Long
+        // horizons (two wavefronts per SIMD, 256 registers each, 15 accumulator tiles): reloaded at the top of every
+        // pass so that they are dead during the matrix-core section instead of being spilled to scratch.
         double M1[9], Sk[9], Am[12], jon[4], ja[4], jb[4];
+        auto load_coeffs = [&]() {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                M1[3 * r + c] = sA[(xr0 + r) * NX + hr0 + c];
-                Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
+                for (int c = 0; c < 3; ++c) {
+                    M1[3 * r + c] = sA[(xr0 + r) * NX + hr0 + c];
+                    Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Am[4 * r + c] = sA[(hr0 + r) * NX + 12 + c];
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Am[4 * r + c] = sA[(hr0 + r) * NX + 12 + c];
-        }
+            for (int i = 0; i < 4; ++i) {
+                jon[i] = sA[(12 + i) * NX + 16 + i];
+                ja[i] = sA[(16 + i) * NX + 12 + i];
+                jb[i] = sA[(16 + i) * NX + 16 + i];
+            }
+        };
+        if constexpr (D::L_IN_LDS) load_coeffs();
+        double sqx[3], sqh[3], sqe[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            jon[i] = sA[(12 + i) * NX + 16 + i];
-            ja[i] = sA[(16 + i) * NX + 12 + i];
-            jb[i] = sA[(16 + i) * NX + 16 + i];
-        }
+        for (int r = 0; r < 3; ++r) { sqx[r] = cfg.sq[yx0 + r]; sqh[r] = cfg.sq[yh0 + r]; sqe[r] = cfg.sq[ye0 + r]; }
+        const double aff = kind == 2 ? 1.0 : 0.0;
+        // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step and the Y
+        // buffer enter as immediate offsets of ds_read_b64
+        const int ylane = (lane >> 4) * D::YS + (lane & 15);
+        constexpr int NPASS = (D::N + 1) / 2;
+        constexpr int BUFSZ = S::YROWS * D::YS;
+        if constexpr (STAMPS) { t_mark = stamp_t1; VS_TOC(3); }  // P1 set-up (coefficient loads)
+
+        // One sweep = the sensitivity recursion over the whole horizon + the SYRK into the accumulator slots
+        // [S0, S1) of this wavefront.  The paper horizon runs one sweep over all slots.  Long horizons run two (the
+        // recursion is cheap next to a SYRK that spills): with 15 accumulator tiles live the matrix-core stream does
+        // not fit the 256 registers a wavefront of a 512-thread workgroup gets.
+        auto sweep = [&](auto s0c, auto s1c) {
+        constexpr int S0 = decltype(s0c)::value, S1 = decltype(s1c)::value, NSL = S1 - S0;
         double xs[3], hs[3], es[3], Ts[4], Tds[4];
         double bh[3], ce[3], bT[4], bTd[4];
 #pragma unroll
@@ -706,31 +689,24 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             bT[i] = kind == 1 ? (i == comp ? sBt[(12 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[12 + i] : 0.0);
             bTd[i] = kind == 1 ? (i == comp ? sBt[(16 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[16 + i] : 0.0);
         }
-        const double aff = kind == 2 ? 1.0 : 0.0;
-        double sqx[3], sqh[3], sqe[3];
+        d4 a[NSL];
+        const double* pa[NSL];
+        const double* pb[NSL];
+        int ts[NSL];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { sqx[r] = cfg.sq[yx0 + r]; sqh[r] = cfg.sq[yh0 + r]; sqe[r] = cfg.sq[ye0 + r]; }
-
-        // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step and the Y
-        // buffer enter as immediate offsets of ds_read_b64
-        const int ylane = (lane >> 4) * D::YS + (lane & 15);
-        const double* pa[TPW];
-        const double* pb[TPW];
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            pa[q] = sY + ylane + 16 * ti[q];
-            pb[q] = sY + ylane + 16 * tj[q];
+        for (int q = 0; q < NSL; ++q) {
+            a[q] = d4{0.0, 0.0, 0.0, 0.0};
+            pa[q] = sY + ylane + 16 * ti[S0 + q];
+            pb[q] = sY + ylane + 16 * tj[S0 + q];
+            ts[q] = tstart[S0 + q];
         }
-
-        constexpr int NPASS = (D::N + 1) / 2;
-        constexpr int BUFSZ = S::YROWS * D::YS;
-        if constexpr (STAMPS) { t_mark = stamp_t1; VS_TOC(3); }  // P1 set-up (coefficient and state loads)
 #pragma unroll 1
         for (int m = 0; m < NPASS; ++m) {
             const int bufoff = (S::NYBUF == 2) ? (m & 1) * BUFSZ : 0;
             double* Yb = sY + bufoff;
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
+            if constexpr (!D::L_IN_LDS) load_coeffs();
 #pragma unroll 1
             for (int par = 0; par < nnodes; ++par) {
                 const int k = 2 * m + par;  // stage k -> node k+1
@@ -784,17 +760,39 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const int last_stage = 2 * m + nnodes - 1;
             int nact = 0;  // scalar: the table is sorted by first stage, so the active slots are a prefix
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) nact += (last_stage >= tstart[q]) ? 1 : 0;
-            if constexpr (TPW <= 12) {
-                if (nnodes == 2) syrk_dispatch<D, TPW, 9>(nact, acc, pa, pb, bufoff);
-                else syrk_dispatch<D, TPW, 5>(nact, acc, pa, pb, bufoff);
-            } else {
-                if (nnodes == 2) syrk_chunk_dispatch<D, TPW, 6, 9>(nact, acc, pa, pb, bufoff);
-                else syrk_chunk_dispatch<D, TPW, 6, 5>(nact, acc, pa, pb, bufoff);
-            }
+            for (int q = 0; q < NSL; ++q) nact += (last_stage >= ts[q]) ? 1 : 0;
+            static_assert(NSL <= 12, "a sweep keeps at most 12 accumulator tiles per wavefront");
+            if (nnodes == 2) syrk_dispatch<D, NSL, 9>(nact, a, pa, pb, bufoff);
+            else syrk_dispatch<D, NSL, 5>(nact, a, pa, pb, bufoff);
             VS_TOC(2);
             // double-buffered Y: one barrier per pass (the next pass writes the other buffer); single buffer: two
             if constexpr (S::NYBUF == 1) __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) acc[S0 + q] = a[q];
+        };  // sweep
+
+        if constexpr (TPW <= 12) {
+            sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, TPW>{});
+        } else {
+            constexpr int SH = (TPW + 1) / 2;
+            const int crow0 = (lane >> 4) * 17 + (lane & 15);
+            sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, SH>{});
+            // park the first half in this instance's workspace slice (each lane re-reads only what it wrote)
+#pragma unroll
+            for (int q = 0; q < SH; ++q) {
+                double* T = Lb + tile_off<D>(ti[q], tj[q]) + crow0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+            }
+            if constexpr (S::NYBUF == 2) __syncthreads();  // the second sweep starts over with Y buffer 0
+            sweep(std::integral_constant<int, SH>{}, std::integral_constant<int, TPW>{});
+#pragma unroll
+            for (int q = 0; q < SH; ++q) {
+                const double* T = Lb + tile_off<D>(ti[q], tj[q]) + crow0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
+            }
         }
         VS_TIC();
     }

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
 pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth"); solver = importlib.import_module(PKG + ".solver")
-cfg = pkg.paper_config()
+cfg = pkg.horizon2x_config() if (len(sys.argv) > 1 and sys.argv[1] == "h2x") else pkg.paper_config()
 X = synth.make_batch(cfg, 256, workload="hover")
 for B in (1, 8, 64, 128, 256, 512):
     Xb = np.tile(X, (max(1, B // 256), 1))[:B] if B > 256 else X[:B]
