@@ -99,7 +99,7 @@ struct Smem {
     static constexpr bool FASTSWEEP = D::L_IN_LDS;
     static constexpr int NJT = D::NU >> 4;           // joint tile rows
     static constexpr int oXinv = oY + (sizeY > sizeM ? sizeY : sizeM);
-    static constexpr int sizeXinv = FASTSWEEP ? NJT * D::TS : 0;
+    static constexpr int sizeXinv = FASTSWEEP ? (NJT + 1) * D::TS : 0;  // + the first throttle tile (box QP, dual form)
     static constexpr int oG = oXinv + sizeXinv;
     static constexpr int sizeG = FASTSWEEP ? (NJT * (NJT - 1) / 2) * D::TS : 0;
     static constexpr int total = oG + sizeG;
@@ -109,6 +109,8 @@ struct Smem {
 
 template <class D>
 VS_DEV int tile_off(int i, int j) { return (i * (i + 1) / 2 + j) * D::TS; }
+template <class D>
+constexpr int tile_off_c(int i, int j) { return (i * (i + 1) / 2 + j) * D::TS; }
 
 // element (gr, gc), gc <= gr, of the lower-triangular tile storage
 template <class D>
@@ -452,7 +454,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
         if constexpr (S::FASTSWEEP) {
             // the other wavefronts idle while wavefront 0 factors panel p: wavefront 1 inverts the diagonal tile
             // finished one panel ago, wavefronts 2 and 3 scale the tiles left of the one finished two panels ago
-            if (W == 1 && p >= 1 && p - 1 < S::NJT)
+            if (W == 1 && p >= 1 && p - 1 <= S::NJT)
                 tile_inverse<D>(sM + tile_off<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
             if ((W == 2 || W == 3) && p >= 3 && p - 2 < S::NJT) {
                 const int pr = p - 2;
@@ -526,6 +528,61 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Box QP, dual form: pieces that depend only on the factor and therefore run in wavefronts that idle during the first
+// (throttle) steps of the backward sweep.  X = L22^-1 for the throttle block: rows 0..15 are the inverse of the first
+// throttle diagonal tile (tile_inverse, during P3); rows [A0, A1) of the second tile row are formed here, lane = column:
+//   x_i = (i == j ? 1 : -sum_{k<i} L22[i][k] x_k) / L22[i][i].   sXr[a * (NV+1) + j] = X[16 + a][j].
+// ------------------------------------------------------------------------------------------------
+template <class D, int A0, int A1>
+VS_DEV void xinv_rows(const double* __restrict__ X6, const double* __restrict__ L76, const double* __restrict__ L77,
+                      const double* __restrict__ invd16, double* __restrict__ sXr, int lane) {
+    constexpr int NVS = D::NV + 1;
+    const int r = lane < D::NV ? lane : D::NV - 1;
+    double xk[16], xr[A1];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double t = X6[k * 17 + (r & 15)];
+        xk[k] = r < 16 ? t : 0.0;
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < A0; ++b2) xr[b2] = sXr[b2 * NVS + r];
+#pragma unroll
+    for (int a2 = A0; a2 < A1; ++a2) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            s0 = fma(L76[a2 * 17 + k], xk[k], s0);  // uniform addresses: LDS broadcasts
+            s1 = fma(L76[a2 * 17 + k + 1], xk[k + 1], s1);
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < a2; ++b2) s0 = fma(L77[a2 * 17 + b2], xr[b2], s0);
+        const double di = invd16[a2];
+        xr[a2] = (r == 16 + a2) ? di : -di * (s0 + s1);
+        if (lane < D::NV) sXr[a2 * NVS + r] = xr[a2];
+    }
+}
+
+// s = L22 (L^-1 g)_v, whose largest entry scales the release tolerance of the box QP (row NZ of the factor holds L^-1 g)
+template <class D>
+VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec, int lane) {
+    constexpr int PV = D::NU >> 4;
+    constexpr int GR = D::NZ - 16 * (PV + 1);  // local row of NZ in tile row PV+1
+    const int r = lane < D::NV ? lane : D::NV - 1;
+    const double* L76 = Lb + tile_off<D>(PV + 1, PV);
+    const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
+    const double* rowp = Lb + tile_off<D>(PV + (r >> 4), PV) + (r & 15) * 17;  // L22[r][c] = rowp[(c>>4)*TS + (c&15)]
+    double sr = 0.0;
+#pragma unroll
+    for (int c = 0; c < D::NV; ++c) {
+        // tile (PV, PV+1) does not exist: that load stays inside tile row PV+1 and is masked out
+        const double lrc = rowp[((c >> 4) && (r >> 4)) ? D::TS + (c & 15) : (c & 15)];
+        const double ellc = c < 16 ? L76[GR * 17 + c] : L77[GR * 17 + (c - 16)];
+        sr = fma(c <= r ? lrc : 0.0, ellc, sr);
+    }
+    if (lane < D::NV) sSvec[r] = sr;
+}
+
+// ------------------------------------------------------------------------------------------------
 // the solve kernel
 // ------------------------------------------------------------------------------------------------
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
@@ -544,7 +601,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         }                                                                                   \
     } while (0)
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long t_mark = 0, stamp_t1 = 0;
+    unsigned long long t_mark = 0, stamp_t1 = 0, rt0 = 0;
+    if constexpr (STAMPS) rt0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz clock: wall time of this instance
 #define VS_TIC()                                                     \
     do {                                                             \
         if constexpr (STAMPS) t_mark = __builtin_amdgcn_s_memtime(); \
@@ -797,7 +855,6 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         VS_TIC();
     }
     __syncthreads();
-    VS_TOC(4);  // waiting for the slowest wavefront of the last pass
     VS_STAMP(2);
 
     // ---------------------------------------------------------------- P2 + P3 (wave-specialised, see cholesky_wave)
@@ -892,6 +949,19 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 w = fma(-colv[k], zk, w);  // lanes j >= k: colv is zero or w is no longer used
             }
             if (lane < 16) sZ[gj] = z;
+        } else if constexpr (S::FASTSWEEP && D::NV > 16 && D::NV <= 32) {
+            // first pass over the throttle tiles: wavefronts 1 and 2 idle while wavefront 0 runs the chain; they form
+            // what the dual box QP would need (second tile row of X = L22^-1 in two halves, the Schur right-hand side)
+            if (!prescribed) {
+                constexpr int NR2 = D::NV - 16, NH = NR2 / 2;
+                double* sXr = sX + D::NV * (D::NV + 1);
+                const double* X6 = sXinv + PV * D::TS;
+                const double* L76 = Lb + tile_off<D>(PV + 1, PV);
+                const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
+                if (wave == 1 && p == D::NT - 1) xinv_rows<D, 0, NH>(X6, L76, L77, sInvD + D::NU + 16, sXr, lane);
+                if (wave == 1 && p == D::NT - 2) xinv_rows<D, NH, NR2>(X6, L76, L77, sInvD + D::NU + 16, sXr, lane);
+                if (wave == 2 && p == D::NT - 1) schur_rhs<D>(Lb, sSvec, lane);
+            }
         }
         __syncthreads();
         if (p > 0) {
@@ -916,13 +986,202 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         const double tolv = 1e-12 * (1.0 + fabs(v));
         const bool viol = valid && !fixed && (v < cfg.vmin - tolv || v > cfg.vmax + tolv);
         const unsigned long long vm = __ballot(viol);
-        if (lane == 0) { sFlags[3] = vm != 0ull; sFlags[1] = VSMPC_STATUS_SOLVED; sFlags[2] = 1; }
+        if (lane == 0) { sFlags[3] = __popcll(vm); sFlags[1] = VSMPC_STATUS_SOLVED; sFlags[2] = 1; }
     }
     __syncthreads();
     const bool need_qp = sFlags[3] != 0;
     VS_STAMP(5);
 
+    // few saturated throttles (the usual case): dual form, cost grows with the number of active bounds;
+    // many: primal form on the Schur complement, cost independent of it
+    constexpr int DUAL_MAX_ACTIVE = 4;
+    const bool use_dual = (D::NV <= 32) && sFlags[3] <= DUAL_MAX_ACTIVE;
     if (need_qp) {
+      if (use_dual) {
+       if constexpr (D::NV <= 32) {
+        // ---- box QP on the throttles, dual form.  With N = the throttles that are not pinned by the hold, P = S_NN^-1
+        // (S = L22 L22^T, so the factor of S_NN is the leading block of L22) and v_u = the sweep's solution, fixing the
+        // set A at its bounds b_A gives  mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.
+        // P = X^T X with X = L22^-1: rows 0..15 of X are the inverse of the first throttle diagonal tile (formed by an
+        // idle wavefront during P3), the remaining rows are formed here; a column of P then is 24 multiply-adds per
+        // lane with no chain, and only the columns some active set needs are ever formed.  The |A| x |A| system is
+        // tiny for the usual one to three saturated throttles.  The sequence of active sets is exactly the
+        // block-pivoting sequence of the primal form.
+        if (wave == 0) {
+            static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
+            constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
+            constexpr int NR2 = D::NV - 16;         // throttle rows in the second tile row
+            double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
+            double* sK = sX;                        // working copy of P_AA (sX / sF are free until P6)
+            double* sXr = sX + D::NV * NVS;         // rows 16.. of X: sXr[a * NVS + j] = X[16 + a][j]
+            static_assert(D::NV * NVS + NR2 * NVS <= D::NXS + NX * D::N, "work arrays fit sX | sF");
+            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
+            const bool valid = lane < D::NV;
+            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
+            const int n = hold ? D::NV - 4 : D::NV;
+            const bool inN = valid && r < n;
+            const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
+            const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
+            const double* X6 = sXinv + PV * D::TS;  // X[i][j], i, j < 16, at i*17 + j; rows 16.. are in sXr (sweep_tile)
+            double gmax = 0.0;
+#pragma unroll
+            for (int c = 0; c < D::NV; ++c) gmax = fmax(gmax, fabs(sSvec[c]));  // uniform addresses, in-order LDS
+            const double gtol = 1e-10 * (1.0 + gmax);
+            const double vu = sZ[D::NU + r];
+            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
+            // backward sweep that just ran.  Apply its flips here; nothing is at a bound yet, so only primal
+            // violations can occur.
+            int state = 0;  // 0 free, -1 at lower, +1 at upper (pinned throttles are outside N altogether)
+            double v = vu;
+            int best, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
+            {
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool vlo = inN && (v < lo - tolv);
+                const bool vhi = inN && (v > hi + tolv);
+                best = __popcll(__ballot(vlo || vhi));
+                if (vlo || vhi) state = vlo ? -1 : 1;
+            }
+            // column r of X restricted to the rows of N (this lane's factor of every P entry it forms)
+            double xc[D::NV];
+#pragma unroll
+            for (int j = 0; j < D::NV; ++j) {
+                const double t = j < 16 ? X6[j * 17 + (r & 15)] : sXr[(j - 16) * NVS + r];
+                xc[j] = (j < 16 ? r < 16 : j < n) ? t : 0.0;
+            }
+            unsigned long long have = 0ull;
+            for (int it = 1; it < cfg.max_as_iter; ++it) {
+                iters = it + 1;
+                const bool isA = inN && state != 0;
+                const unsigned long long Amask = __ballot(isA);
+                // columns of P for the newly active throttles: P[i][b] = sum_{j < n} X[j][i] X[j][b]
+                unsigned long long need = Amask & ~have;
+                have |= need;
+                while (need) {
+                    const int b = __ffsll((long long)need) - 1;
+                    need &= need - 1;
+                    double p0 = 0.0, p1 = 0.0;
+                    if (b < 16) {  // X[j][b] = 0 for j < 16 <= b
+#pragma unroll
+                        for (int j = 0; j < 16; j += 2) {
+                            p0 = fma(xc[j], X6[j * 17 + b], p0);            // uniform addresses: LDS broadcasts
+                            p1 = fma(xc[j + 1], X6[(j + 1) * 17 + b], p1);
+                        }
+                    }
+#pragma unroll
+                    for (int a2 = 0; a2 < NR2; ++a2) p0 = fma(xc[16 + a2], sXr[a2 * NVS + b], p0);
+                    if (valid) sP[b * NVS + r] = p0 + p1;
+                }
+                double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
+                double mu = 0.0;
+                const int ka = __popcll(Amask);
+                if (ka <= 4) {
+                    // up to four active bounds: the system is solved redundantly in every lane on wave-uniform values
+                    // (symmetric elimination on the lower triangle, identity rows pad the unused slots)
+                    int idx[4];
+                    unsigned long long m = Amask;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        idx[q] = m ? __ffsll((long long)m) - 1 : 0;
+                        m &= m - 1;
+                    }
+                    double K[4][4], d[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double dq = readlane_f64(bb, idx[q]);
+                        d[q] = q < ka ? dq : 0.0;
+#pragma unroll
+                        for (int c = 0; c <= q; ++c) {
+                            const double kqc = sP[idx[c] * NVS + idx[q]];  // uniform address: LDS broadcast
+                            K[q][c] = q < ka ? kqc : (q == c ? 1.0 : 0.0);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bad |= (j < ka) && !(K[j][j] > 0.0);
+                        const double ip = fast_rcp(K[j][j]);
+#pragma unroll
+                        for (int i = j + 1; i < 4; ++i) {
+                            const double f = K[i][j] * ip;
+                            d[i] = fma(-f, d[j], d[i]);
+#pragma unroll
+                            for (int c = j + 1; c <= i; ++c) K[i][c] = fma(-f, K[c][j], K[i][c]);
+                        }
+                    }
+                    double x[4];
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        double t = d[j];
+#pragma unroll
+                        for (int c = j + 1; c < 4; ++c) t = fma(-K[c][j], x[c], t);
+                        x[j] = t * fast_rcp(K[j][j]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mu = (q < ka && lane == idx[q]) ? x[q] : mu;
+                } else {
+                    // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
+                    if (isA) {
+                        unsigned long long m = Amask;
+                        while (m) {
+                            const int c = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            sK[r * NVS + c] = sP[c * NVS + r];
+                        }
+                    }
+                    for (unsigned long long pm = Amask; pm; pm &= pm - 1) {
+                        const int j = __ffsll((long long)pm) - 1;
+                        const double piv = sK[j * NVS + j];
+                        bad |= !(piv > 0.0);
+                        const double bj = readlane_f64(bb, j);
+                        if (isA && lane > j) {
+                            const double f = sK[r * NVS + j] * fast_rcp(piv);
+                            bb -= f * bj;
+                            for (unsigned long long m = pm & (pm - 1); m; m &= m - 1) {
+                                const int c = __ffsll((long long)m) - 1;
+                                sK[r * NVS + c] -= f * sK[j * NVS + c];
+                            }
+                        }
+                    }
+                    for (unsigned long long pm = Amask; pm;) {
+                        const int j = 63 - __clzll((long long)pm);
+                        pm &= ~(1ull << j);
+                        const double xj = readlane_f64(bb, j) * fast_rcp(sK[j * NVS + j]);
+                        if (lane == j) mu = xj;
+                        if (isA && lane < j) bb -= sK[r * NVS + j] * xj;
+                    }
+                }
+                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
+                // v_N = v_u,N - P[:,A] mu
+                v = vu;
+                for (unsigned long long m = Amask; m; m &= m - 1) {
+                    const int b = __ffsll((long long)m) - 1;
+                    const double mub = readlane_f64(mu, b);
+                    if (inN) v -= sP[b * NVS + r] * mub;
+                }
+                const double grad = -mu;  // gradient of the QP at the throttles that sit on a bound
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool isF = inN && state == 0;
+                const bool vlo = isF && (v < lo - tolv);
+                const bool vhi = isF && (v > hi + tolv);
+                const bool rlo = isA && state == -1 && grad < -gtol;
+                const bool rhi = isA && state == 1 && grad > gtol;
+                const bool inf = vlo || vhi || rlo || rhi;
+                const unsigned long long imask = __ballot(inf);
+                const int ninf = __popcll(imask);
+                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
+                bool pick = inf;
+                if (ninf < best) { best = ninf; patience = 3; }
+                else if (patience > 0) { --patience; }
+                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
+                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
+            }
+            if (valid) {
+                v = fixed ? lo : (state < 0 ? lo : (state > 0 ? hi : v));  // bound variables sit exactly on their bound
+                sZ[D::NU + lane] = v;
+            }
+            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+        }
+       }
+      } else {
         // Schur complement S = L22 L22^T, s = L22 (L^-1 g)_v
         for (int e = tid; e < D::NV * D::NV; e += D::BLOCK) {
             const int r = e / D::NV, c = e % D::NV;
@@ -952,13 +1211,23 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
             const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
             int state = fixed ? -1 : 0;  // 0 free, -1 at lower, +1 at upper
-            double v = 0.0;
             double gmax = fabs(svr);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
             const double gtol = 1e-10 * (1.0 + gmax);
-            int best = D::NV + 1, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 0;
-            for (int it = 0; it < cfg.max_as_iter; ++it) {
+            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
+            // backward sweep that just ran (its throttles are in sZ).  Apply its flips here instead of repeating
+            // the solve; nothing is at a bound yet, so only primal violations can occur.
+            double v = sZ[D::NU + r];
+            int best, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 1;
+            {
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool vlo = valid && state == 0 && (v < lo - tolv);
+                const bool vhi = valid && state == 0 && (v > hi + tolv);
+                best = __popcll(__ballot(vlo || vhi));
+                if (vlo || vhi) state = vlo ? -1 : 1;
+            }
+            for (int it = 1; it < cfg.max_as_iter; ++it) {
                 iters = it + 1;
                 const bool isF = valid && state == 0;
                 const unsigned long long Fmask = __ballot(isF);
@@ -1018,10 +1287,26 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             }
             if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
         }
+      }
         __syncthreads();
         VS_STAMP(6);
+        if constexpr (S::FASTSWEEP) {
+            if (tid < D::NU) {
+                const double* Lc = Lb + tile_off<D>(PV, tid >> 4) + (tid & 15);  // rows NU.. of column tid, tile by tile
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < D::NV; c += 2) {
+                    a0 = fma(Lc[((c >> 4) * (tile_off<D>(PV + 1, 0) - tile_off<D>(PV, 0))) + (c & 15) * 17], sZ[D::NU + c], a0);
+                    a1 = fma(Lc[(((c + 1) >> 4) * (tile_off<D>(PV + 1, 0) - tile_off<D>(PV, 0))) + ((c + 1) & 15) * 17],
+                             sZ[D::NU + c + 1], a1);
+                }
+                sW[tid] = -Lb[lower_at<D>(D::NZ, tid)] - (a0 + a1);  // y_U - L21^T v
+            }
+            __syncthreads();
+        } else {
 #pragma unroll 1
-        for (int p = D::NT - 1; p >= (S::FASTSWEEP ? PV : 0); --p) sweep_tile(p, true);
+            for (int p = D::NT - 1; p >= 0; --p) sweep_tile(p, true);
+        }
     } else {
         VS_STAMP(6);
         if constexpr (!S::FASTSWEEP) {
@@ -1221,8 +1506,11 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     }
     VS_STAMP(9);
     if constexpr (STAMPS) {
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
+            t_acc[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+            t_acc[4] = rt0;  // absolute start (global 100 MHz counter): start skew across the workgroups of a launch
             for (int i = 0; i < 6; ++i) stamps[size_t(blockIdx.x) * 16 + 10 + i] = t_acc[i];
+        }
     }
 #undef VS_STAMP
 #undef VS_TIC

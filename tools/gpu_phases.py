@@ -21,7 +21,12 @@ for wl, B in ((("hover", 256), ("takeoff", 256)) if len(_s.argv) > 1 else (("hov
     print(f"== {wl} batch {B}: total cycles/instance median {np.median(tot):.0f} (s_memtime ticks), span of launch {(st[:,9].max()-st[:,0].min())}")
     for i, n in enumerate(names):
         print(f"  {n:38s} median {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f}  share {100*np.median(d[:, i])/np.median(tot):5.1f}%")
-    sub = ["P1 propagate (wave 0)", "P1 barrier wait", "P1 MFMA", "P1 set-up", "P1 tail wait", "unused"]
+    sub = ["P1 propagate (wave 0)", "P1 barrier wait", "P1 MFMA", "P1 set-up", "start stamp (s_memrealtime)", "wall time, 10 ns ticks (s_memrealtime)"]
     for i, n in enumerate(sub):
         print(f"    {n:36s} median {np.median(st[:, 10 + i]):9.0f}")
+    start = st[:, 14] - st[:, 14].min(); end = start + st[:, 15]
+    print(f"    start skew over the launch: median {np.median(start)/100:.1f} us, p90 {np.percentile(start,90)/100:.1f}, max {start.max()/100:.1f} us; last end - first start {end.max()/100:.1f} us")
+    if B <= 256: print("    start offsets by workgroup id (us):", np.round(start[::16] / 100.0, 1))
+    wall_us = np.median(st[:, 15]) / 100.0
+    print(f"    shader clock while this instance ran: {np.median(tot) / wall_us / 1e3:.3f} GHz ({wall_us:.1f} us per instance)")
     m.close()
