@@ -528,40 +528,6 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Box QP, dual form: pieces that depend only on the factor and therefore run in wavefronts that idle during the first
-// (throttle) steps of the backward sweep.  X = L22^-1 for the throttle block: rows 0..15 are the inverse of the first
-// throttle diagonal tile (tile_inverse, during P3); rows [A0, A1) of the second tile row are formed here, lane = column:
-//   x_i = (i == j ? 1 : -sum_{k<i} L22[i][k] x_k) / L22[i][i].   sXr[a * (NV+1) + j] = X[16 + a][j].
-// ------------------------------------------------------------------------------------------------
-template <class D, int A0, int A1>
-VS_DEV void xinv_rows(const double* __restrict__ X6, const double* __restrict__ L76, const double* __restrict__ L77,
-                      const double* __restrict__ invd16, double* __restrict__ sXr, int lane) {
-    constexpr int NVS = D::NV + 1;
-    const int r = lane < D::NV ? lane : D::NV - 1;
-    double xk[16], xr[A1];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const double t = X6[k * 17 + (r & 15)];
-        xk[k] = r < 16 ? t : 0.0;
-    }
-#pragma unroll
-    for (int b2 = 0; b2 < A0; ++b2) xr[b2] = sXr[b2 * NVS + r];
-#pragma unroll
-    for (int a2 = A0; a2 < A1; ++a2) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-            s0 = fma(L76[a2 * 17 + k], xk[k], s0);  // uniform addresses: LDS broadcasts
-            s1 = fma(L76[a2 * 17 + k + 1], xk[k + 1], s1);
-        }
-#pragma unroll
-        for (int b2 = 0; b2 < a2; ++b2) s0 = fma(L77[a2 * 17 + b2], xr[b2], s0);
-        const double di = invd16[a2];
-        xr[a2] = (r == 16 + a2) ? di : -di * (s0 + s1);
-        if (lane < D::NV) sXr[a2 * NVS + r] = xr[a2];
-    }
-}
-
 // s = L22 (L^-1 g)_v, whose largest entry scales the release tolerance of the box QP (row NZ of the factor holds L^-1 g)
 template <class D>
 VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec, int lane) {
@@ -949,19 +915,6 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 w = fma(-colv[k], zk, w);  // lanes j >= k: colv is zero or w is no longer used
             }
             if (lane < 16) sZ[gj] = z;
-        } else if constexpr (S::FASTSWEEP && D::NV > 16 && D::NV <= 32) {
-            // first pass over the throttle tiles: wavefronts 1 and 2 idle while wavefront 0 runs the chain; they form
-            // what the dual box QP would need (second tile row of X = L22^-1 in two halves, the Schur right-hand side)
-            if (!prescribed) {
-                constexpr int NR2 = D::NV - 16, NH = NR2 / 2;
-                double* sXr = sX + D::NV * (D::NV + 1);
-                const double* X6 = sXinv + PV * D::TS;
-                const double* L76 = Lb + tile_off<D>(PV + 1, PV);
-                const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
-                if (wave == 1 && p == D::NT - 1) xinv_rows<D, 0, NH>(X6, L76, L77, sInvD + D::NU + 16, sXr, lane);
-                if (wave == 1 && p == D::NT - 2) xinv_rows<D, NH, NR2>(X6, L76, L77, sInvD + D::NU + 16, sXr, lane);
-                if (wave == 2 && p == D::NT - 1) schur_rhs<D>(Lb, sSvec, lane);
-            }
         }
         __syncthreads();
         if (p > 0) {
@@ -977,8 +930,78 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         }
     };
 
+    // the dual box QP and the chain-free first pass need the throttle block to span exactly two tile rows
+    constexpr bool DUALQP = S::FASTSWEEP && D::NT - 2 == PV && D::NV >= 20 && D::NV <= 32;
+    if constexpr (DUALQP) {
+        // The throttle block spans two tile rows.  Last tile row: only its KL = NZ - 16 (NT-1) throttle rows take part
+        // (gradient row and padding have z = 0), the hold pins sit here.  First throttle tile row: no pins, and the
+        // inverse of its diagonal tile is at hand (X66 from P3), so z = X66^T w needs no chain.
+        constexpr int PL = D::NT - 1, KL = D::NZ - 16 * PL;
+        static_assert(KL == D::NV - 16 && KL >= 4, "pins live in the last tile row");
+        const double* X6 = sXinv + PV * D::TS;
+        const double* L77 = Lb + tile_off<D>(PL, PL);
+        if (wave == 0) {
+            const int j = lane & 15;
+            const int gj = 16 * PL + j;
+            const double* Tpp = L77 + j;
+            double colv[KL];
+#pragma unroll
+            for (int k = 0; k < KL; ++k) colv[k] = Tpp[k * 17];  // entries k < j are zero (stored upper part)
+            double w = sW[gj];
+            const bool fix = (j >= KL) || (hold && j >= KL - 4);
+            const double inv_eff = fix ? 0.0 : sInvD[gj];
+            const double zadd = (fix && j < KL) ? sZ[gj] : 0.0;
+            double z = 0.0;
+#pragma unroll
+            for (int k = KL - 1; k >= 0; --k) {
+                const double zk = readlane_f64(fma(w, inv_eff, zadd), k);
+                z = (j == k) ? zk : z;
+                w = fma(-colv[k], zk, w);
+            }
+            if (lane < 16) sZ[gj] = z;
+        }
+        __syncthreads();
+        if (tid < 16 * PL) {
+            const double* T = Lb + tile_off<D>(PL, tid >> 4) + (tid & 15);
+            const double* zp = sZ + 16 * PL;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < KL; k += 2) {
+                a0 = fma(T[k * 17], zp[k], a0);
+                a1 = fma(T[(k + 1) * 17], zp[k + 1], a1);
+            }
+            sW[tid] -= a0 + a1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (lane < 16) {
+                const double* wp = sW + 16 * PV;
+                double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    z0 = fma(X6[i * 17 + lane], wp[i], z0);
+                    z1 = fma(X6[(i + 1) * 17 + lane], wp[i + 1], z1);
+                }
+                sZ[16 * PV + lane] = z0 + z1;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * PV) {
+            const double* T = Lb + tile_off<D>(PV, tid >> 4) + (tid & 15);
+            const double* zp = sZ + 16 * PV;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                a0 = fma(T[k * 17], zp[k], a0);
+                a1 = fma(T[(k + 1) * 17], zp[k + 1], a1);
+            }
+            sW[tid] -= a0 + a1;
+        }
+        __syncthreads();
+    } else {
 #pragma unroll 1
-    for (int p = D::NT - 1; p >= PV; --p) sweep_tile(p, false);
+        for (int p = D::NT - 1; p >= PV; --p) sweep_tile(p, false);
+    }
     if (wave == 0) {
         const bool valid = lane < D::NV;
         const double v = sZ[D::NU + (valid ? lane : 0)];
@@ -995,10 +1018,10 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     // few saturated throttles (the usual case): dual form, cost grows with the number of active bounds;
     // many: primal form on the Schur complement, cost independent of it
     constexpr int DUAL_MAX_ACTIVE = 4;
-    const bool use_dual = (D::NV <= 32) && sFlags[3] <= DUAL_MAX_ACTIVE;
+    const bool use_dual = DUALQP && sFlags[3] <= DUAL_MAX_ACTIVE;
     if (need_qp) {
       if (use_dual) {
-       if constexpr (D::NV <= 32) {
+       if constexpr (DUALQP) {
         // ---- box QP on the throttles, dual form.  With N = the throttles that are not pinned by the hold, P = S_NN^-1
         // (S = L22 L22^T, so the factor of S_NN is the leading block of L22) and v_u = the sweep's solution, fixing the
         // set A at its bounds b_A gives  mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.
@@ -1007,6 +1030,48 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         // lane with no chain, and only the columns some active set needs are ever formed.  The |A| x |A| system is
         // tiny for the usual one to three saturated throttles.  The sequence of active sets is exactly the
         // block-pivoting sequence of the primal form.
+        {
+            // second tile row of X by all wavefronts:  [X76 | X77] = [-X77 (L76 X66) | L77^-1]
+            constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
+            double* sXr = sX + D::NV * NVS;                               // sXr[a * NVS + j] = X[16 + a][j]
+            double* sT = sX;                                              // T = L76 X66, NR2 x 16 (dead before sK is used)
+            const double* X6 = sXinv + PV * D::TS;
+            const double* L76 = Lb + tile_off<D>(PV + 1, PV);
+            const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
+            if (tid < 16 * NR2) {
+                const int a2 = tid >> 4, j = tid & 15;
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {                         // X66[k][j] = 0 for k < j (stored zeros)
+                    t0 = fma(L76[a2 * 17 + k], X6[k * 17 + j], t0);
+                    t1 = fma(L76[a2 * 17 + k + 1], X6[(k + 1) * 17 + j], t1);
+                }
+                sT[a2 * 16 + j] = t0 + t1;
+            } else if (tid >= 128 && tid < 128 + NR2) {
+                const int c = tid - 128;                                  // column c of X77 = L77^-1
+                double x[NR2];
+#pragma unroll
+                for (int i = 0; i < NR2; ++i) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) sum = fma(L77[i * 17 + k], (k >= c) ? x[k] : 0.0, sum);
+                    const double di = sInvD[D::NU + 16 + i];
+                    x[i] = (i == c) ? di : ((i > c) ? -di * sum : 0.0);
+                    sXr[i * NVS + 16 + c] = x[i];
+                }
+            } else if (wave == 3) {
+                schur_rhs<D>(Lb, sSvec, lane);
+            }
+            __syncthreads();
+            if (tid < 16 * NR2) {
+                const int a2 = tid >> 4, j = tid & 15;
+                double t = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < NR2; ++b2) t = fma(sXr[a2 * NVS + 16 + b2], sT[b2 * 16 + j], t);  // X77[a][b] = 0, b > a
+                sXr[a2 * NVS + j] = -t;
+            }
+            __syncthreads();
+        }
         if (wave == 0) {
             static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
             constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
