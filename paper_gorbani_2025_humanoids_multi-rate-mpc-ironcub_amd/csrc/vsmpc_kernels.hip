@@ -528,6 +528,49 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// K x K symmetric positive definite system P_AA mu = rhs_A of the dual box QP, K <= 4, all lanes redundantly on
+// wave-uniform values (symmetric elimination on the lower triangle).  sP[b * NVS + i] = P[i][b]; the K set bits of
+// `mask` are the active indices; lane idx[q] returns mu_q, every other lane 0.
+template <int K, int NVS>
+VS_DEV double small_spd_solve(const double* __restrict__ sP, unsigned long long mask, double rhs, int lane, int& bad) {
+    int idx[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        idx[q] = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+    }
+    double A[K][K], d[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        d[q] = readlane_f64(rhs, idx[q]);
+#pragma unroll
+        for (int c = 0; c <= q; ++c) A[q][c] = sP[idx[c] * NVS + idx[q]];  // uniform address: LDS broadcast
+    }
+    double ip[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bad |= !(A[j][j] > 0.0);
+        ip[j] = fast_rcp(A[j][j]);
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            const double f = A[i][j] * ip[j];
+            d[i] = fma(-f, d[j], d[i]);
+#pragma unroll
+            for (int c = j + 1; c <= i; ++c) A[i][c] = fma(-f, A[c][j], A[i][c]);
+        }
+    }
+    double x[K], mu = 0.0;
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+        double t = d[j];
+#pragma unroll
+        for (int c = j + 1; c < K; ++c) t = fma(-A[c][j], x[c], t);
+        x[j] = t * ip[j];
+        mu = (lane == idx[j]) ? x[j] : mu;
+    }
+    return mu;
+}
+
 // s = L22 (L^-1 g)_v, whose largest entry scales the release tolerance of the box QP (row NZ of the factor holds L^-1 g)
 template <class D>
 VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec, int lane) {
@@ -1140,48 +1183,13 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 double mu = 0.0;
                 const int ka = __popcll(Amask);
                 if (ka <= 4) {
-                    // up to four active bounds: the system is solved redundantly in every lane on wave-uniform values
-                    // (symmetric elimination on the lower triangle, identity rows pad the unused slots)
-                    int idx[4];
-                    unsigned long long m = Amask;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        idx[q] = m ? __ffsll((long long)m) - 1 : 0;
-                        m &= m - 1;
+                    // up to four active bounds: solved redundantly in every lane on wave-uniform values
+                    switch (ka) {
+                        case 1: mu = small_spd_solve<1, D::NV + 1>(sP, Amask, bb, lane, bad); break;
+                        case 2: mu = small_spd_solve<2, D::NV + 1>(sP, Amask, bb, lane, bad); break;
+                        case 3: mu = small_spd_solve<3, D::NV + 1>(sP, Amask, bb, lane, bad); break;
+                        default: mu = small_spd_solve<4, D::NV + 1>(sP, Amask, bb, lane, bad); break;
                     }
-                    double K[4][4], d[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double dq = readlane_f64(bb, idx[q]);
-                        d[q] = q < ka ? dq : 0.0;
-#pragma unroll
-                        for (int c = 0; c <= q; ++c) {
-                            const double kqc = sP[idx[c] * NVS + idx[q]];  // uniform address: LDS broadcast
-                            K[q][c] = q < ka ? kqc : (q == c ? 1.0 : 0.0);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bad |= (j < ka) && !(K[j][j] > 0.0);
-                        const double ip = fast_rcp(K[j][j]);
-#pragma unroll
-                        for (int i = j + 1; i < 4; ++i) {
-                            const double f = K[i][j] * ip;
-                            d[i] = fma(-f, d[j], d[i]);
-#pragma unroll
-                            for (int c = j + 1; c <= i; ++c) K[i][c] = fma(-f, K[c][j], K[i][c]);
-                        }
-                    }
-                    double x[4];
-#pragma unroll
-                    for (int j = 3; j >= 0; --j) {
-                        double t = d[j];
-#pragma unroll
-                        for (int c = j + 1; c < 4; ++c) t = fma(-K[c][j], x[c], t);
-                        x[j] = t * fast_rcp(K[j][j]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mu = (q < ka && lane == idx[q]) ? x[q] : mu;
                 } else {
                     // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
                     if (isA) {
