@@ -661,13 +661,17 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     // ---------------------------------------------------------------- P0
     {   // 16 B per lane: the record stride (NIN doubles) and the LDS base are multiples of 16 B
         static_assert(D::NIN % 2 == 0 && D::NVAR % 2 == 0 && D::NXS % 2 == 0 && D::NU % 2 == 0, "double2 I/O");
+        // the record's HBM round trip (~1 us) is overlapped with the LDS initialisation: loads first, dependent stores last
+        static_assert(D::NIN / 2 <= D::BLOCK, "one 16-byte load per thread covers the record");
         const double2* in2 = reinterpret_cast<const double2*>(in + size_t(inst) * D::NIN);
         double2* sIn2 = reinterpret_cast<double2*>(sIn);
-        for (int i = tid; i < D::NIN / 2; i += D::BLOCK) sIn2[i] = in2[i];
+        double2 rec = make_double2(0.0, 0.0);
+        if (tid < D::NIN / 2) rec = in2[tid];
+        if (tid < 4) sFlags[tid] = 0;
+        if (tid < D::N) sDt[tid] = cfg.dt[tid];
+        for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
+        if (tid < D::NIN / 2) sIn2[tid] = rec;
     }
-    if (tid < 4) sFlags[tid] = 0;
-    if (tid < D::N) sDt[tid] = cfg.dt[tid];
-    for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
     __syncthreads();
     p0_linearize<D, false>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);
 
