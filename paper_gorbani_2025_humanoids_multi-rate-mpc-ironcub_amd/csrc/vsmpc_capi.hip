@@ -44,6 +44,11 @@ struct vsmpc_rollout {
     double* d_talpha;
     double* d_log;
     int log_ticks;
+    RolloutCtl* d_ctl;        // per-run control block read by advance_kernel (log destination, tick base)
+    int ticks_done;           // ticks since the last reset (the same for every instance)
+    hipStream_t own_stream;   // used when the caller passes the null stream (which cannot be captured)
+    hipGraphExec_t gexec;     // GRAPH_TICKS ticks (3 launches each) captured once, replayed per chunk
+    int graph_state;          // 0 not built yet, 1 ready, -1 capture unavailable (direct launches only)
 };
 
 namespace {
@@ -434,6 +439,8 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
     if (e == hipSuccess) e = hipMemcpy(r->d_tvel, traj_vel, size_t(n_traj) * 3 * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(r->d_talpha, traj_alpha, size_t(n_alpha) * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(r->d_tick, 0, B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&r->d_ctl, sizeof(RolloutCtl));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         vsmpc_rollout_destroy(r);
         return e == hipErrorOutOfMemory ? VSMPC_ERR_ALLOC : hip_fail(e, "vsmpc_rollout_create");
@@ -452,6 +459,9 @@ void vsmpc_rollout_destroy(vsmpc_rollout* r) {
     if (r->d_tvel) (void)hipFree(r->d_tvel);
     if (r->d_talpha) (void)hipFree(r->d_talpha);
     if (r->d_log) (void)hipFree(r->d_log);
+    if (r->d_ctl) (void)hipFree(r->d_ctl);
+    if (r->gexec) (void)hipGraphExecDestroy(r->gexec);
+    if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
 }
 
@@ -462,15 +472,57 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
     HIP_TRY(hipMemcpy(r->d_state, state, B * VSMPC_PLANT_STATE * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(r->d_params, params, B * VSMPC_PLANT_PARAMS * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(r->d_tick, 0, B * sizeof(int)));
+    r->ticks_done = 0;
     return VSMPC_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+constexpr int GRAPH_TICKS = 25;  // ticks per captured graph (75 kernel nodes)
+
+// one closed-loop tick: three launches on `s`, the stream order is the only synchronisation the loop needs
+hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
+    vsmpc_handle* h = r->h;
+    hipError_t e = launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha,
+                                 h->d_in, s);
+    if (e == hipSuccess)
+        e = launch_solve(h->variant, h->dev, h->d_in, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr, nullptr,
+                         nullptr, h->d_ws, s);
+    if (e == hipSuccess)
+        e = launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
+                           r->d_talpha, r->d_ctl, r->substeps, s);
+    return e;
+}
+
+// Captures GRAPH_TICKS ticks into a graph (every launch argument is tick-invariant: tick counters, log destination and
+// tick base live in device memory).  Launch-bound loop -> one graph launch per chunk instead of 75 kernel launches.
+void build_tick_graph(vsmpc_rollout* r, hipStream_t s) {
+    r->graph_state = -1;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipError_t e = hipSuccess;
+    for (int t = 0; t < GRAPH_TICKS && e == hipSuccess; ++t) e = enqueue_tick(r, s);
+    hipGraph_t graph = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(s, &graph);
+    if (e == hipSuccess && e2 == hipSuccess && graph != nullptr &&
+        hipGraphInstantiate(&r->gexec, graph, nullptr, nullptr, 0) == hipSuccess)
+        r->graph_state = 1;
+    else
+        (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+}
+
+}  // namespace
+
+extern "C" {
 
 int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
     if (r == nullptr || ticks < 0) return VSMPC_ERR_INVALID_ARG;
     if (ticks == 0) return VSMPC_OK;
     vsmpc_handle* h = r->h;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->own_stream;
     const size_t row = size_t(r->batch) * VSMPC_ROLLOUT_LOG;
     if (log != nullptr && r->log_ticks < ticks) {
         if (r->d_log) (void)hipFree(r->d_log);
@@ -480,17 +532,17 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
         if (e != hipSuccess) return e == hipErrorOutOfMemory ? VSMPC_ERR_ALLOC : hip_fail(e, "vsmpc_rollout_run");
         r->log_ticks = ticks;
     }
-    // three launches per tick, all on `s`: the stream order is the only synchronisation the loop needs
-    for (int t = 0; t < ticks; ++t) {
-        HIP_TRY(launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha,
-                              h->d_in, s));
-        HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                             nullptr, nullptr, h->d_ws, s));
-        HIP_TRY(launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
-                               r->d_talpha, log ? r->d_log + size_t(t) * row : nullptr, r->substeps, s));
-    }
+    const RolloutCtl ctl = {log ? r->d_log : nullptr, r->ticks_done, 0};
+    HIP_TRY(hipMemcpyAsync(r->d_ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `ctl` lives on this stack frame
+    int t = 0;
+    if (ticks >= GRAPH_TICKS && r->graph_state == 0) build_tick_graph(r, s);
+    if (r->graph_state == 1)
+        for (; ticks - t >= GRAPH_TICKS; t += GRAPH_TICKS) HIP_TRY(hipGraphLaunch(r->gexec, s));
+    for (; t < ticks; ++t) HIP_TRY(enqueue_tick(r, s));
     if (log) HIP_TRY(hipMemcpyAsync(log, r->d_log, size_t(ticks) * row * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    r->ticks_done += ticks;
     return VSMPC_OK;
 }
 

@@ -27,11 +27,16 @@ struct RolloutDev {
     int n_in, n_ref, ratio, n_traj, n_alpha;
     double period_mpc, alpha_dt;
 };
+struct RolloutCtl {   // device-resident per-run control block of the rollout
+    double* log;      // [ticks of this run][batch][VSMPC_ROLLOUT_LOG] or nullptr
+    int tick_base;    // tick counter at the start of the run
+    int pad;
+};
 hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,
                          const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* rec,
                          hipStream_t stream);
 hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
-                          const int* status, const int* iters, const double* traj_alpha, double* log_row, int substeps,
+                          const int* status, const int* iters, const double* traj_alpha, const RolloutCtl* ctl, int substeps,
                           hipStream_t stream);
 
 }  // namespace vsmpc

@@ -48,179 +48,225 @@ VS_DEV double interp_clamped(const double* __restrict__ tr, int n, double pos) {
     return tr[i] + f * (tr[i + 1] - tr[i]);
 }
 
-// one thread per instance (the work is ~400 FLOP and 294 stores: the solve dominates the tick by 3 orders of magnitude)
-__global__ __launch_bounds__(64) void record_kernel(RolloutDev rd, int batch, const double* __restrict__ state,
-                                                     const double* __restrict__ params, const int* __restrict__ tick,
-                                                     const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
-                                                     const double* __restrict__ traj_alpha, double* __restrict__ rec) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per instance.  The plant state and parameters are staged through LDS with coalesced loads, the record
+// is assembled in LDS by all 64 lanes (every field is a short independent expression) and written out coalesced.
+constexpr int RO_BLOCK = 64;
+
+VS_DEV void stage_in(const double* __restrict__ g, double* __restrict__ l, int n, int lane) {
+    for (int i = lane; i < n; i += RO_BLOCK) l[i] = g[i];
+}
+
+__global__ __launch_bounds__(RO_BLOCK) void record_kernel(RolloutDev rd, int batch, const double* __restrict__ state,
+                                                           const double* __restrict__ params, const int* __restrict__ tick,
+                                                           const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
+                                                           const double* __restrict__ traj_alpha, double* __restrict__ rec) {
+    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], R[9], om[3];
+    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES];
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
-    const double* s = state + size_t(b) * VSMPC_PLANT_STATE;
-    const double* p = params + size_t(b) * VSMPC_PLANT_PARAMS;
-    double* r = rec + size_t(b) * rd.n_in;
+    stage_in(state + size_t(b) * VSMPC_PLANT_STATE, s, VSMPC_PLANT_STATE, lane);
+    stage_in(params + size_t(b) * VSMPC_PLANT_PARAMS, p, VSMPC_PLANT_PARAMS, lane);
+    __syncthreads();
     const int tk = tick[b] + int(p[VSMPC_PP_TICK0]);
-    double R[9], IB[9], IBi[9];
-    rot_from_rpy(s + VSMPC_PS_RPY, R);
-    for (int i = 0; i < 9; ++i) IB[i] = p[VSMPC_PP_INERTIA_B + i];
-    inv3(IB, IBi);
-    double omega[3];
-    for (int i = 0; i < 3; ++i) omega[i] = IBi[3 * i] * s[VSMPC_PS_HANG] + IBi[3 * i + 1] * s[VSMPC_PS_HANG + 1] + IBi[3 * i + 2] * s[VSMPC_PS_HANG + 2];
     const double m = p[VSMPC_PP_MASS];
+    if (lane == 0) {
+        rot_from_rpy(s + VSMPC_PS_RPY, R);
+    } else if (lane == 1) {
+        double IBi[9];
+        inv3(p + VSMPC_PP_INERTIA_B, IBi);
+        for (int i = 0; i < 3; ++i)
+            om[i] = IBi[3 * i] * s[VSMPC_PS_HANG] + IBi[3 * i + 1] * s[VSMPC_PS_HANG + 1] + IBi[3 * i + 2] * s[VSMPC_PS_HANG + 2];
+    }
+    __syncthreads();
     // reference window: one column per large step, sample index advances every `ratio` ticks (costsVSMPC.cpp:124-165)
     const int idx0 = tk / rd.ratio;
-    for (int j = 0; j < rd.n_ref; ++j) {
+    for (int e = lane; e < 12 * rd.n_ref; e += RO_BLOCK) {
+        const int j = e / 12, i = e - 12 * j;
         int idx = idx0 + j;
         idx = idx < rd.n_traj ? idx : rd.n_traj - 1;
-        double* xr = r + VSMPC_IN_XREF + 12 * j;
-        double v[3];
-        for (int i = 0; i < 3; ++i) {
-            xr[i] = p[VSMPC_PP_PINIT + i] + traj_pos[3 * idx + i];      // m_initialCoMPos + positionCoM (costsVSMPC.cpp:105-106)
-            v[i] = m * traj_vel[3 * idx + i];
-            xr[6 + i] = p[VSMPC_PP_RPYINIT + i];                        // m_initialRPY + RPY trajectory (all zero)
-            xr[9 + i] = 0.0;
+        double v;
+        if (i < 3) {
+            v = p[VSMPC_PP_PINIT + i] + traj_pos[3 * idx + i];      // m_initialCoMPos + positionCoM (costsVSMPC.cpp:105-106)
+        } else if (i < 6) {                                          // R^T m v_ref (:107-109)
+            const int c = i - 3;
+            v = R[c] * (m * traj_vel[3 * idx]) + R[3 + c] * (m * traj_vel[3 * idx + 1]) + R[6 + c] * (m * traj_vel[3 * idx + 2]);
+        } else if (i < 9) {
+            v = p[VSMPC_PP_RPYINIT + i - 6];                         // m_initialRPY + RPY trajectory (all zero)
+        } else {
+            v = 0.0;
         }
-        for (int i = 0; i < 3; ++i) xr[3 + i] = R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2];  // R^T m v_ref (:107-109)
+        r[VSMPC_IN_XREF + e] = v;
     }
-    // X0 (constraintsVSMPC.cpp:206-230); |rpy| stays below pi in these rollouts, so unwrapped RPY == RPY
-    for (int i = 0; i < 20; ++i) r[VSMPC_IN_X0 + i] = s[i];
-    for (int i = 0; i < 3; ++i) {
-        r[VSMPC_IN_X0 + 20 + i] = s[VSMPC_PS_P + i] - r[VSMPC_IN_XREF + i];
-        r[VSMPC_IN_X0 + 23 + i] = s[VSMPC_PS_RPY + i] - r[VSMPC_IN_XREF + 6 + i];
-        r[VSMPC_IN_OMEGA + i] = omega[i];
-        r[VSMPC_IN_RPY + i] = s[VSMPC_PS_RPY + i];
-        r[VSMPC_IN_PREF + i] = r[VSMPC_IN_XREF + i];
-        r[VSMPC_IN_RPYINIT + i] = p[VSMPC_PP_RPYINIT + i];
-    }
-    r[VSMPC_IN_MASS] = m;
-    for (int i = 0; i < 9; ++i) r[VSMPC_IN_WRB + i] = R[i];
-    r[VSMPC_IN_ALPHA] = interp_clamped(traj_alpha, rd.n_alpha, double(tk) * rd.period_mpc / rd.alpha_dt);
-    r[VSMPC_IN_GRAV] = 0.0; r[VSMPC_IN_GRAV + 1] = 0.0; r[VSMPC_IN_GRAV + 2] = -9.81;
     // A_mom(q) = A_mom0 + sum_j DJ[j] (q_j - q_ref0_j); Lambda column j = DJ[j] T at the measured thrust
     // (the reference recomputes both from the kinematics each tick, systemDynamicsVSMPC.cpp:159-206,304,321-350)
-    for (int i = 0; i < 24; ++i) r[VSMPC_IN_AMOM + i] = p[VSMPC_PP_AMOM0 + i];
-    for (int j = 0; j < 8; ++j) {
-        const double* D = p + VSMPC_PP_DJ + 24 * j;
-        const double dqj = s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j];
-        for (int i = 0; i < 24; ++i) r[VSMPC_IN_AMOM + i] += D[i] * dqj;
-        for (int row = 0; row < 6; ++row) {
-            double acc = 0.0;
-            for (int c = 0; c < 4; ++c) acc += D[4 * row + c] * s[VSMPC_PS_T + c];
-            if (row < 3) r[VSMPC_IN_LLIN + 8 * row + j] = acc;
-            else r[VSMPC_IN_LANG + 8 * (row - 3) + j] = acc;
-        }
+    if (lane < 24) {
+        double acc = p[VSMPC_PP_AMOM0 + lane];
+        for (int j = 0; j < 8; ++j) acc += p[VSMPC_PP_DJ + 24 * j + lane] * (s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j]);
+        r[VSMPC_IN_AMOM + lane] = acc;
     }
-    for (int i = 0; i < 3; ++i)       // I_G = R I_B R^T (world-oriented locked inertia)
-        for (int j = 0; j < 3; ++j) {
-            double acc = 0.0;
-            for (int a = 0; a < 3; ++a)
-                for (int c = 0; c < 3; ++c) acc += R[3 * i + a] * IB[3 * a + c] * R[3 * j + c];
-            r[VSMPC_IN_INERTIA + 3 * i + j] = acc;
-        }
-    for (int i = 0; i < 4; ++i) {
+    if (lane < 48) {
+        const int row = lane >> 3, j = lane & 7;   // row 0..5 of DJ[j] T
+        double acc = 0.0;
+        for (int c = 0; c < 4; ++c) acc += p[VSMPC_PP_DJ + 24 * j + 4 * row + c] * s[VSMPC_PS_T + c];
+        if (row < 3) r[VSMPC_IN_LLIN + 8 * row + j] = acc;
+        else r[VSMPC_IN_LANG + 8 * (row - 3) + j] = acc;
+    }
+    if (lane >= 48 && lane < 57) {                  // I_G = R I_B R^T (world-oriented locked inertia)
+        const int i = (lane - 48) / 3, j = (lane - 48) % 3;
+        double acc = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) acc += R[3 * i + a] * p[VSMPC_PP_INERTIA_B + 3 * a + c] * R[3 * j + c];
+        r[VSMPC_IN_INERTIA + 3 * i + j] = acc;
+    }
+    // X0 (constraintsVSMPC.cpp:206-230); |rpy| stays below pi in these rollouts, so unwrapped RPY == RPY
+    if (lane < 20) r[VSMPC_IN_X0 + lane] = s[lane];
+    if (lane >= 20 && lane < 29) r[VSMPC_IN_WRB + lane - 20] = R[lane - 20];
+    if (lane >= 32 && lane < 36) {
+        const int i = lane - 32;
         r[VSMPC_IN_T0 + i] = s[VSMPC_PS_T + i];          // useEstimatedThrust = true (systemDynamicsVSMPC.cpp:401-404)
         r[VSMPC_IN_TD0 + i] = s[VSMPC_PS_TD + i];
         r[VSMPC_IN_UPREV + i] = s[VSMPC_PS_U + i];
         r[VSMPC_IN_TDES + i] = s[VSMPC_PS_TDES + i];
         r[VSMPC_IN_TDDES + i] = s[VSMPC_PS_TDDES + i];
     }
-    for (int i = 0; i < 8; ++i) r[VSMPC_IN_QERR + i] = s[VSMPC_PS_Q + i] - p[VSMPC_PP_QREF0 + i];
-    r[VSMPC_IN_HOLD] = (tk % rd.ratio) != (rd.ratio - 1) ? 1.0 : 0.0;   // constraintsVSMPC.cpp:351,366-372
+    if (lane >= 36 && lane < 44) r[VSMPC_IN_QERR + lane - 36] = s[VSMPC_PS_Q + lane - 36] - p[VSMPC_PP_QREF0 + lane - 36];
+    if (lane >= 44 && lane < 47) {
+        const int i = lane - 44;
+        r[VSMPC_IN_OMEGA + i] = om[i];
+        r[VSMPC_IN_RPY + i] = s[VSMPC_PS_RPY + i];
+        r[VSMPC_IN_RPYINIT + i] = p[VSMPC_PP_RPYINIT + i];
+        r[VSMPC_IN_GRAV + i] = i == 2 ? -9.81 : 0.0;
+    }
+    if (lane == 47) {
+        r[VSMPC_IN_MASS] = m;
+        r[VSMPC_IN_ALPHA] = interp_clamped(traj_alpha, rd.n_alpha, double(tk) * rd.period_mpc / rd.alpha_dt);
+        r[VSMPC_IN_HOLD] = (tk % rd.ratio) != (rd.ratio - 1) ? 1.0 : 0.0;   // constraintsVSMPC.cpp:351,366-372
+    }
+    __syncthreads();
+    if (lane < 3) {                                  // needs the reference window's first column
+        r[VSMPC_IN_X0 + 20 + lane] = s[VSMPC_PS_P + lane] - r[VSMPC_IN_XREF + lane];
+        r[VSMPC_IN_X0 + 23 + lane] = s[VSMPC_PS_RPY + lane] - r[VSMPC_IN_XREF + 6 + lane];
+        r[VSMPC_IN_PREF + lane] = r[VSMPC_IN_XREF + lane];
+    }
+    __syncthreads();
+    double* out = rec + size_t(b) * rd.n_in;
+    for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
 }
 
-__global__ __launch_bounds__(64) void advance_kernel(RolloutDev rd, int batch, double* __restrict__ state,
-                                                      const double* __restrict__ params, int* __restrict__ tick,
-                                                      const double* __restrict__ fm, const int* __restrict__ status,
-                                                      const int* __restrict__ iters, const double* __restrict__ traj_alpha,
-                                                      double* __restrict__ log_row, int substeps) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per instance: staging and the joint-dependent jet map in parallel, the short ODE integration in lane 0
+// on registers, coalesced write-back.
+__global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int batch, double* __restrict__ state,
+                                                            const double* __restrict__ params, int* __restrict__ tick,
+                                                            const double* __restrict__ fm, const int* __restrict__ status,
+                                                            const int* __restrict__ iters, const double* __restrict__ traj_alpha,
+                                                            const RolloutCtl* __restrict__ ctl, int substeps) {
+    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9];
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
-    double* s = state + size_t(b) * VSMPC_PLANT_STATE;
-    const double* p = params + size_t(b) * VSMPC_PLANT_PARAMS;
-    const double* f = fm + size_t(b) * VSMPC_FM_SIZE;
+    stage_in(state + size_t(b) * VSMPC_PLANT_STATE, s, VSMPC_PLANT_STATE, lane);
+    stage_in(params + size_t(b) * VSMPC_PLANT_PARAMS, p, VSMPC_PLANT_PARAMS, lane);
+    stage_in(fm + size_t(b) * VSMPC_FM_SIZE, f, VSMPC_FM_SIZE, lane);
     const int st = status[b];
+    const int tick_before = tick[b];
+    __syncthreads();
     if (st == VSMPC_STATUS_SOLVED) {  // variableSamplingMPC.cpp:91-108
-        for (int i = 0; i < 8; ++i) s[VSMPC_PS_Q + i] += f[VSMPC_FM_DQ + i];
-        for (int i = 0; i < 4; ++i) {
+        if (lane < 8) s[VSMPC_PS_Q + lane] += f[VSMPC_FM_DQ + lane];
+        if (lane >= 8 && lane < 12) {
+            const int i = lane - 8;
             s[VSMPC_PS_U + i] = f[VSMPC_FM_THROTTLE + i];
             s[VSMPC_PS_TDES + i] = f[VSMPC_FM_THRUST + i];
             s[VSMPC_PS_TDDES + i] = f[VSMPC_FM_THRUSTDOT + i];
         }
     }
-    const int tk = tick[b] + int(p[VSMPC_PP_TICK0]);
-    const double m = p[VSMPC_PP_MASS];
-    double IB[9], IBi[9];
-    for (int i = 0; i < 9; ++i) IB[i] = p[VSMPC_PP_INERTIA_B + i];
-    inv3(IB, IBi);
-    double x[20];
-    for (int i = 0; i < 20; ++i) x[i] = s[i];
-    double Aq[24];  // A_mom(q): the joints only move at the tick boundary
-    for (int i = 0; i < 24; ++i) Aq[i] = p[VSMPC_PP_AMOM0 + i];
-    for (int j = 0; j < 8; ++j) {
-        const double dqj = s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j];
-        for (int i = 0; i < 24; ++i) Aq[i] += p[VSMPC_PP_DJ + 24 * j + i] * dqj;
+    __syncthreads();
+    if (lane < 24) {  // A_mom(q): the joints only move at the tick boundary
+        double acc = p[VSMPC_PP_AMOM0 + lane];
+        for (int j = 0; j < 8; ++j) acc += p[VSMPC_PP_DJ + 24 * j + lane] * (s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j]);
+        Aq[lane] = acc;
+    } else if (lane == 24) {
+        inv3(p + VSMPC_PP_INERTIA_B, IBi);
     }
-    double vthr[4];
-    for (int i = 0; i < 4; ++i) vthr[i] = Jet::v_of_throttle(s[VSMPC_PS_U + i]);
-    const double h = rd.period_mpc / double(substeps);
-    for (int ss = 0; ss < substeps; ++ss) {
-        const double t = (double(tk) + double(ss) / double(substeps)) * rd.period_mpc;
-        const double alpha = interp_clamped(traj_alpha, rd.n_alpha, t / rd.alpha_dt);
-        const bool dist = t >= p[VSMPC_PP_DIST_T0] && t < p[VSMPC_PP_DIST_T1];
-        double R[9];
-        rot_from_rpy(x + 6, R);
-        double om[3], d[20];
-        for (int i = 0; i < 3; ++i) om[i] = IBi[3 * i] * x[9] + IBi[3 * i + 1] * x[10] + IBi[3 * i + 2] * x[11];
-        for (int i = 0; i < 3; ++i) d[i] = (R[3 * i] * x[3] + R[3 * i + 1] * x[4] + R[3 * i + 2] * x[5]) / m;     // p' = R h_lin / m
-        const double cl[3] = {om[1] * x[5] - om[2] * x[4], om[2] * x[3] - om[0] * x[5], om[0] * x[4] - om[1] * x[3]};   // omega x h_lin
-        const double ca[3] = {om[1] * x[11] - om[2] * x[10], om[2] * x[9] - om[0] * x[11], om[0] * x[10] - om[1] * x[9]};
-        for (int r = 0; r < 3; ++r) {
-            double fl = -cl[r] + alpha * m * (R[6 + r] * (-9.81));     // alpha m R^T g, g = (0,0,-9.81)
-            double fa = -ca[r];
-            for (int j = 0; j < 4; ++j) { fl += Aq[4 * r + j] * x[12 + j]; fa += Aq[4 * (3 + r) + j] * x[12 + j]; }
-            if (dist) {
-                fl += R[r] * p[VSMPC_PP_DIST_F] + R[3 + r] * p[VSMPC_PP_DIST_F + 1] + R[6 + r] * p[VSMPC_PP_DIST_F + 2];
-                fa += p[VSMPC_PP_DIST_TAU + r];
+    __syncthreads();
+    if (lane == 0) {
+        const int tk = tick_before + int(p[VSMPC_PP_TICK0]);
+        const double m = p[VSMPC_PP_MASS];
+        double x[20], A[24], Ii[9], vthr[4];
+        for (int i = 0; i < 20; ++i) x[i] = s[i];
+        for (int i = 0; i < 24; ++i) A[i] = Aq[i];
+        for (int i = 0; i < 9; ++i) Ii[i] = IBi[i];
+        for (int i = 0; i < 4; ++i) vthr[i] = Jet::v_of_throttle(s[VSMPC_PS_U + i]);
+        const double h = rd.period_mpc / double(substeps);
+        for (int ss = 0; ss < substeps; ++ss) {
+            const double t = (double(tk) + double(ss) / double(substeps)) * rd.period_mpc;
+            const double alpha = interp_clamped(traj_alpha, rd.n_alpha, t / rd.alpha_dt);
+            const bool dist = t >= p[VSMPC_PP_DIST_T0] && t < p[VSMPC_PP_DIST_T1];
+            double sr, cr, sp, cp, sy, cy;
+            sincos(x[6], &sr, &cr); sincos(x[7], &sp, &cp); sincos(x[8], &sy, &cy);
+            const double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                                 sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                                 -sp,     cp * sr,                cp * cr};
+            double om[3], d[20];
+            for (int i = 0; i < 3; ++i) om[i] = Ii[3 * i] * x[9] + Ii[3 * i + 1] * x[10] + Ii[3 * i + 2] * x[11];
+            for (int i = 0; i < 3; ++i) d[i] = (R[3 * i] * x[3] + R[3 * i + 1] * x[4] + R[3 * i + 2] * x[5]) / m;     // p' = R h_lin / m
+            const double cl[3] = {om[1] * x[5] - om[2] * x[4], om[2] * x[3] - om[0] * x[5], om[0] * x[4] - om[1] * x[3]};   // omega x h_lin
+            const double ca[3] = {om[1] * x[11] - om[2] * x[10], om[2] * x[9] - om[0] * x[11], om[0] * x[10] - om[1] * x[9]};
+            for (int r = 0; r < 3; ++r) {
+                double fl = -cl[r] + alpha * m * (R[6 + r] * (-9.81));     // alpha m R^T g, g = (0,0,-9.81)
+                double fa = -ca[r];
+                for (int j = 0; j < 4; ++j) { fl += A[4 * r + j] * x[12 + j]; fa += A[4 * (3 + r) + j] * x[12 + j]; }
+                if (dist) {
+                    fl += R[r] * p[VSMPC_PP_DIST_F] + R[3 + r] * p[VSMPC_PP_DIST_F + 1] + R[6 + r] * p[VSMPC_PP_DIST_F + 2];
+                    fa += p[VSMPC_PP_DIST_TAU + r];
+                }
+                d[3 + r] = fl;
+                d[9 + r] = fa;
             }
-            d[3 + r] = fl;
-            d[9 + r] = fa;
+            const double tp = sp / cp;
+            d[6] = om[0] + sr * tp * om[1] + cr * tp * om[2];      // rpy' = W^-1 omega (systemDynamicsVSMPC.cpp:140-147)
+            d[7] = cr * om[1] - sr * om[2];
+            d[8] = (sr * om[1] + cr * om[2]) / cp;
+            for (int i = 0; i < 4; ++i) {                           // T'' = sigma_T (f + g v(u))  (JetModel.cpp:29-64)
+                const double Tb = Jet::stdT(x[12 + i]), Tdb = Jet::stdTd(x[16 + i]);
+                d[12 + i] = x[16 + i];
+                d[16 + i] = Jet::sgT * (Jet::f(Tb, Tdb) + Jet::g(Tb, Tdb) * vthr[i]);
+            }
+            for (int i = 0; i < 20; ++i) x[i] += h * d[i];
         }
-        double sr, cr, sp, cp;
-        sincos(x[6], &sr, &cr); sincos(x[7], &sp, &cp);
-        const double tp = sp / cp;
-        d[6] = om[0] + sr * tp * om[1] + cr * tp * om[2];      // rpy' = W^-1 omega (systemDynamicsVSMPC.cpp:140-147)
-        d[7] = cr * om[1] - sr * om[2];
-        d[8] = (sr * om[1] + cr * om[2]) / cp;
-        for (int i = 0; i < 4; ++i) {                           // T'' = sigma_T (f + g v(u))  (JetModel.cpp:29-64)
-            const double Tb = Jet::stdT(x[12 + i]), Tdb = Jet::stdTd(x[16 + i]);
-            d[12 + i] = x[16 + i];
-            d[16 + i] = Jet::sgT * (Jet::f(Tb, Tdb) + Jet::g(Tb, Tdb) * vthr[i]);
-        }
-        for (int i = 0; i < 20; ++i) x[i] += h * d[i];
+        for (int i = 0; i < 20; ++i) s[i] = x[i];
+        tick[b] = tick_before + 1;
     }
-    for (int i = 0; i < 20; ++i) s[i] = x[i];
-    tick[b] += 1;
-    if (log_row != nullptr) {
-        double* lg = log_row + size_t(b) * VSMPC_ROLLOUT_LOG;
-        for (int i = 0; i < 3; ++i) { lg[i] = x[i]; lg[3 + i] = x[6 + i]; }
-        for (int i = 0; i < 4; ++i) { lg[6 + i] = x[12 + i]; lg[10 + i] = s[VSMPC_PS_U + i]; }
-        lg[14] = double(st);
-        lg[15] = iters ? double(iters[b]) : 0.0;
+    __syncthreads();
+    double* so = state + size_t(b) * VSMPC_PLANT_STATE;
+    for (int i = lane; i < VSMPC_PLANT_STATE; i += RO_BLOCK) so[i] = s[i];
+    // the log destination comes from a device-side control block, so the launch arguments are the same for every
+    // tick and a captured graph of ticks can be replayed
+    double* log = ctl->log;
+    if (log != nullptr && lane < VSMPC_ROLLOUT_LOG) {
+        const int row = tick_before - ctl->tick_base;   // ticks since the start of this run
+        double v;
+        if (lane < 3) v = s[lane];
+        else if (lane < 6) v = s[6 + lane - 3];
+        else if (lane < 10) v = s[12 + lane - 6];
+        else if (lane < 14) v = s[VSMPC_PS_U + lane - 10];
+        else if (lane == 14) v = double(st);
+        else v = iters ? double(iters[b]) : 0.0;
+        log[(size_t(row) * batch + b) * VSMPC_ROLLOUT_LOG + lane] = v;
     }
 }
 
 hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,
                          const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* rec,
                          hipStream_t stream) {
-    hipLaunchKernelGGL(record_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, rd, batch, state, params, tick,
+    hipLaunchKernelGGL(record_kernel, dim3(batch), dim3(RO_BLOCK), 0, stream, rd, batch, state, params, tick,
                        traj_pos, traj_vel, traj_alpha, rec);
     return hipGetLastError();
 }
 
 hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
-                          const int* status, const int* iters, const double* traj_alpha, double* log_row, int substeps,
+                          const int* status, const int* iters, const double* traj_alpha, const RolloutCtl* ctl, int substeps,
                           hipStream_t stream) {
-    hipLaunchKernelGGL(advance_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, rd, batch, state, params, tick, fm,
-                       status, iters, traj_alpha, log_row, substeps);
+    hipLaunchKernelGGL(advance_kernel, dim3(batch), dim3(RO_BLOCK), 0, stream, rd, batch, state, params, tick, fm,
+                       status, iters, traj_alpha, ctl, substeps);
     return hipGetLastError();
 }
 
