@@ -77,6 +77,33 @@ def test_condensed_hessian_and_factor(mpc, ref, synth, layout):
     assert relerr(Lf[120, :120], np.linalg.solve(Lr, gr)) < 1e-11
 
 
+def test_box_qp_both_formulations_match_oracle(mpc, ref, synth, layout):
+    """Instances whose throttles saturate, picked from 768 take-off / Monte-Carlo states so that every size of the
+    first violated set from 1 up to 12+ occurs: sizes <= 4 run the dual form (P = X^T X, register solver), larger
+    ones the primal form on the Schur complement.  Solution, multipliers' consequence (bounds hit exactly) and the
+    active-set iteration count are compared with the oracle for each."""
+    cfg, rcfg = layout.paper_config(), ref.paper_config()
+    recs = np.concatenate([synth.make_batch(cfg, 384, workload="takeoff", seed0=9000),
+                           synth.make_batch(cfg, 384, workload="montecarlo", seed0=9500)])
+    x, fm, status, iters = mpc.solve(recs)
+    assert (status == layout.STATUS_SOLVED).all()
+    vmin, vmax = ref.throttle_bounds(rcfg)
+    v = x[:, 564:588]
+    nact = ((v == vmin) | (v == vmax)).sum(axis=1)          # bound variables sit exactly on their bound
+    qp = np.where(iters > 1)[0]
+    assert len(qp) >= 40
+    chosen = []
+    for k in sorted(set(nact[qp])):                          # up to three instances per active-set size
+        chosen += list(qp[nact[qp] == k][:3])
+    sizes = sorted(set(nact[chosen]))
+    assert min(sizes) <= 1 and max(sizes) >= 12 and len([k for k in sizes if 2 <= k <= 6]) >= 3, sizes
+    for b in chosen:
+        xr, _, itr, _ = ref.solve_instance(rcfg, recs[b])
+        assert relerr(x[b], xr) < TOL, (b, nact[b], relerr(x[b], xr))
+        assert iters[b] == itr, (b, nact[b], iters[b], itr)
+        assert v[b].min() >= vmin and v[b].max() <= vmax
+
+
 @pytest.mark.parametrize("workload", ["hover", "takeoff", "montecarlo"])
 def test_solve_matches_oracle(mpc, ref, synth, layout, workload):
     cfg, rcfg = layout.paper_config(), ref.paper_config()
