@@ -306,27 +306,40 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll                                                              // in-range tile and are never stored
         for (int c = 0; c < 16; ++c) a[s][c] = T[s][c];
     }
-    int bad = 0;
-    double myinv = 0.0;
+    double dmin = 1.0;     // all pivots positive <=> min(pivots) > 0; a NaN pivot (fmin skips it) makes every later
+                           // pivot and the last reciprocal square root NaN, which is checked at the end
+    double invs[NPIV];     // wave-uniform reciprocal square roots of the pivots
+    // software-pipelined pivots: the next pivot is complete as soon as the first column of this pivot's update is
+    // done, so its reciprocal square root (a ~75-cycle dependent chain) is issued there and overlaps the rest of the
+    // update instead of following it
+    double d = readlane_f64(a[0][0], 0);
+    double inv = fast_rsqrt(d);
 #pragma unroll
     for (int j = 0; j < NPIV; ++j) {
-        const double d = readlane_f64(a[0][j], j);
-        bad |= !(d > 0.0);
-        const double inv = fast_rsqrt(d);
-        myinv = (lane == j) ? inv : myinv;
+        dmin = fmin(dmin, d);
+        invs[j] = inv;
         double l[NSLOT];
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) { l[s] = a[s][j] * inv; a[s][j] = l[s]; }
+        if (j + 1 < 16) {
+            const double lcj = readlane_f64(l[0], j + 1);
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
+            for (int s = 0; s < NSLOT; ++s) a[s][j + 1] = fma(-l[s], lcj, a[s][j + 1]);
+            if (j + 1 < NPIV) {
+                d = readlane_f64(a[0][j + 1], j + 1);
+                inv = fast_rsqrt(d);
+            }
+        }
+#pragma unroll
+        for (int c = j + 2; c < 16; ++c) {
             const double lcj = readlane_f64(l[0], c);
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) a[s][c] = fma(-l[s], lcj, a[s][c]);
         }
     }
-    if (ok[0]) {
+    if (ok[0]) {  // the part of the diagonal tile above the diagonal holds leftovers: its readers mask it
 #pragma unroll
-        for (int c = 0; c < 16; ++c) T[0][c] = (lane >= 16 || c <= lane) ? a[0][c] : 0.0;
+        for (int c = 0; c < 16; ++c) T[0][c] = a[0][c];
     }
 #pragma unroll
     for (int s = 1; s < NSLOT; ++s)
@@ -334,8 +347,11 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll
             for (int c = 0; c < 16; ++c) T[s][c] = a[s][c];
         }
-    if (lane < NPIV) sInvD[16 * p + lane] = myinv;
-    return bad;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NPIV; ++j) sInvD[16 * p + j] = invs[j];
+    }
+    return !(dmin > 0.0) || !(invs[NPIV - 1] == invs[NPIV - 1]);
 }
 
 // runtime-p wrapper (kept out of line for long horizons so that the unrolled panel loop stays small)
@@ -947,7 +963,10 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const double* Tpp = Lb + tile_off<D>(p, p) + j;
             double colv[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) colv[k] = Tpp[k * 17];  // entries k < j are zero (stored upper part)
+            for (int k = 0; k < 16; ++k) {  // column j of L_pp; above the diagonal the tile holds leftovers
+                const double t = Tpp[k * 17];
+                colv[k] = k >= j ? t : 0.0;
+            }
             double w = sW[gj];
             // z_j = w_j * inv_eff + zadd: solved rows use 1/L_jj, prescribed rows (pinned or already fixed
             // throttles, gradient row, padding) use inv_eff = 0 and their value; branch-free in the chain
@@ -993,7 +1012,10 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const double* Tpp = L77 + j;
             double colv[KL];
 #pragma unroll
-            for (int k = 0; k < KL; ++k) colv[k] = Tpp[k * 17];  // entries k < j are zero (stored upper part)
+            for (int k = 0; k < KL; ++k) {  // column j of L_pp; above the diagonal the tile holds leftovers
+                const double t = Tpp[k * 17];
+                colv[k] = k >= j ? t : 0.0;
+            }
             double w = sW[gj];
             const bool fix = (j >= KL) || (hold && j >= KL - 4);
             const double inv_eff = fix ? 0.0 : sInvD[gj];
