@@ -673,6 +673,19 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     // tile storage of the factor: LDS, or this instance's slice of the global workspace
     double* Lb = D::L_IN_LDS ? sM : gLws + size_t(inst) * D::L_WORKSPACE_DOUBLES;
 
+    // tiles of the lower triangle are dealt round-robin to the wavefronts: tile t -> wave t % NWAVES, slot t / NWAVES.
+    // The (wave-uniform) coordinates come from a table in constant memory; requested first so that the scalar loads'
+    // cold-cache latency is spent under P0.
+    constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
+    int ti[TPW], tj[TPW], tstart[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = q * D::NWAVES + wave;  // entry of the stage-sorted table (padded with never-active dummies)
+        ti[q] = kTileTab<D>.ti[t];
+        tj[q] = kTileTab<D>.tj[t];
+        tstart[q] = kTileTab<D>.ts[t];
+    }
+
     VS_STAMP(0);
     // ---------------------------------------------------------------- P0
     {   // 16 B per lane: the record stride (NIN doubles) and the LDS base are multiples of 16 B
@@ -694,18 +707,9 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     VS_STAMP(1);
     if constexpr (STAMPS) stamp_t1 = __builtin_amdgcn_s_memtime();
     // ---------------------------------------------------------------- P1 condense
-    // tiles of the lower triangle are dealt round-robin to the four wavefronts: tile t -> wave t%4, slot t/4
-    constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
     d4 acc[TPW];
-    int ti[TPW], tj[TPW], tstart[TPW];  // scalar (wave-uniform) tile coordinates from the compile-time table
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-        const int t = q * D::NWAVES + wave;  // entry of the stage-sorted table (padded with never-active dummies)
-        ti[q] = kTileTab<D>.ti[t];
-        tj[q] = kTileTab<D>.tj[t];
-        tstart[q] = kTileTab<D>.ts[t];
-    }
+    for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
 
     {
         // thread (half, col): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy);
@@ -761,20 +765,28 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         constexpr int S0 = decltype(s0c)::value, S1 = decltype(s1c)::value, NSL = S1 - S0;
         double xs[3], hs[3], es[3], Ts[4], Tds[4];
         double bh[3], ce[3], bT[4], bTd[4];
+        // unconditional loads (every address is valid for every column), selected afterwards: conditional loads
+        // become branches and the LDS latencies add up instead of overlapping
+        const int jc = comp & 7, tc = comp & 3;
+        const bool aff_col = kind == 2, jnt_col = kind == 0, thr_col = kind == 1;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            xs[r] = kind == 2 ? sIn[VSMPC_IN_X0 + xr0 + r] : 0.0;
-            hs[r] = kind == 2 ? sIn[VSMPC_IN_X0 + hr0 + r] : 0.0;
-            es[r] = kind == 2 ? sIn[VSMPC_IN_X0 + er0 + r] : 0.0;
-            bh[r] = kind == 0 ? sBj[(hr0 + r) * NJ + comp] : (kind == 2 ? sC[hr0 + r] : 0.0);
-            ce[r] = kind == 2 ? sC[er0 + r] : 0.0;
+            const double x0 = sIn[VSMPC_IN_X0 + xr0 + r], h0 = sIn[VSMPC_IN_X0 + hr0 + r], e0 = sIn[VSMPC_IN_X0 + er0 + r];
+            const double bj = sBj[(hr0 + r) * NJ + jc], ch = sC[hr0 + r], cee = sC[er0 + r];
+            xs[r] = aff_col ? x0 : 0.0;
+            hs[r] = aff_col ? h0 : 0.0;
+            es[r] = aff_col ? e0 : 0.0;
+            bh[r] = jnt_col ? bj : (aff_col ? ch : 0.0);
+            ce[r] = aff_col ? cee : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            Ts[i] = kind == 2 ? sIn[VSMPC_IN_X0 + 12 + i] : 0.0;
-            Tds[i] = kind == 2 ? sIn[VSMPC_IN_X0 + 16 + i] : 0.0;
-            bT[i] = kind == 1 ? (i == comp ? sBt[(12 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[12 + i] : 0.0);
-            bTd[i] = kind == 1 ? (i == comp ? sBt[(16 + i) * NTH + i] : 0.0) : (kind == 2 ? sC[16 + i] : 0.0);
+            const double t0 = sIn[VSMPC_IN_X0 + 12 + i], td0 = sIn[VSMPC_IN_X0 + 16 + i];
+            const double b12 = sBt[(12 + i) * NTH + i], b16 = sBt[(16 + i) * NTH + i], c12 = sC[12 + i], c16 = sC[16 + i];
+            Ts[i] = aff_col ? t0 : 0.0;
+            Tds[i] = aff_col ? td0 : 0.0;
+            bT[i] = thr_col ? (i == tc ? b12 : 0.0) : (aff_col ? c12 : 0.0);
+            bTd[i] = thr_col ? (i == tc ? b16 : 0.0) : (aff_col ? c16 : 0.0);
         }
         d4 a[NSL];
         const double* pa[NSL];
