@@ -806,44 +806,52 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
             if constexpr (!D::L_IN_LDS) load_coeffs();
-#pragma unroll 1
-            for (int par = 0; par < nnodes; ++par) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                if (par >= nnodes) break;  // the last pass of an odd horizon has one node
                 const int k = 2 * m + par;  // stage k -> node k+1
                 const double dt = sDt[k];
+                // reference of this node (affine column only; column map costsVSMPC.cpp:191-200), requested before the
+                // recursion so that the LDS latency is spent under it
+                const int rc = k < D::NS ? 0 : k - D::NS;
+                const double* xr = sIn + VSMPC_IN_XREF + rc * 12;  // uniform address: LDS broadcast
+                double xrx[3], xrh[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { xrx[r] = xr[yx0 + r]; xrh[r] = xr[yh0 + r]; }
                 const bool actJ = (kind == 0 && joint_block_of_stage<D>(k) == blk) || kind == 2;
                 const bool actT = (kind == 1 && throttle_block_of_stage<D>(k) == blk) || kind == 2;
+                // input activity as 0/1 factors inside the multiply-adds (a 64-bit select costs two instructions);
+                // the jet part of the momentum rate is a chain of its own so that more chains are in flight
+                const double mJ = actJ ? 1.0 : 0.0, mT = actT ? 1.0 : 0.0;
                 double dx[3], dh[3], de[3], dT[4], dTd[4];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    double a0 = 0.0, a1 = actJ ? bh[r] : 0.0;
+                    double a0 = M1[3 * r] * hs[0], a1 = mJ * bh[r], a2 = Am[4 * r] * Ts[0];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        a0 += M1[3 * r + c] * hs[c];
-                        a1 += Sk[3 * r + c] * hs[c];
-                    }
+                    for (int c = 1; c < 3; ++c) a0 = fma(M1[3 * r + c], hs[c], a0);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) a1 += Am[4 * r + c] * Ts[c];
+                    for (int c = 0; c < 3; ++c) a1 = fma(Sk[3 * r + c], hs[c], a1);
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) a2 = fma(Am[4 * r + c], Ts[c], a2);
                     dx[r] = a0;
-                    dh[r] = a1;
+                    dh[r] = a1 + a2;
                     de[r] = xs[r] + ce[r];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dT[i] = jon[i] * Tds[i] + (actT ? bT[i] : 0.0);
-                    dTd[i] = ja[i] * Ts[i] + jb[i] * Tds[i] + (actT ? bTd[i] : 0.0);
+                    dT[i] = fma(jon[i], Tds[i], mT * bT[i]);
+                    dTd[i] = fma(ja[i], Ts[i], fma(jb[i], Tds[i], mT * bTd[i]));
                 }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { xs[r] += dt * dx[r]; hs[r] += dt * dh[r]; es[r] += dt * de[r]; }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { Ts[i] += dt * dT[i]; Tds[i] += dt * dTd[i]; }
                 // Y rows of this node: sqrt(Q) (S_k - xref_k on the affine column); column map costsVSMPC.cpp:191-200
-                const int rc = k < D::NS ? 0 : k - D::NS;
-                const double* xr = sIn + VSMPC_IN_XREF + rc * 12;  // uniform address: LDS broadcast
                 double* Yn = Yb + 18 * par * D::YS + col;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    const double vx = fma(-aff, xr[yx0 + r], xs[r]);  // aff = 1 on the affine column, else 0
-                    const double vh = fma(-aff, xr[yh0 + r], hs[r]);
+                    const double vx = fma(-aff, xrx[r], xs[r]);  // aff = 1 on the affine column, else 0
+                    const double vh = fma(-aff, xrh[r], hs[r]);
                     Yn[(yx0 + r) * D::YS] = sqx[r] * vx;
                     Yn[(yh0 + r) * D::YS] = sqh[r] * vh;
                     Yn[(ye0 + r) * D::YS] = sqe[r] * es[r];
