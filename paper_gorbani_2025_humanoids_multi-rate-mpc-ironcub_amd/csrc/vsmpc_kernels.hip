@@ -1488,7 +1488,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         // their trajectories over through sX (LDS operations of a wavefront execute in order).
         // Every chain first pulls a chunk of CHK stages of its forcing terms into registers (the loads cannot be
         // hoisted past the trajectory stores by the compiler), then runs the recursion on registers.
-        constexpr int CHK = 9;
+        constexpr int CHK = D::N <= 20 ? D::N : 9;  // short horizons: the whole horizon in one register chunk
         // (1) jets: lane i < 4 carries (T_i, Tdot_i)
         if (lane < NTH) {
             const int i = lane;
