@@ -806,7 +806,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
             if constexpr (!D::L_IN_LDS) load_coeffs();
-#pragma unroll
+            // both nodes unrolled when registers allow (their loads and chains interleave); long horizons keep a loop
+#pragma clang loop unroll_count(D::L_IN_LDS ? 2 : 1)
             for (int par = 0; par < 2; ++par) {
                 if (par >= nnodes) break;  // the last pass of an odd horizon has one node
                 const int k = 2 * m + par;  // stage k -> node k+1
