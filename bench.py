@@ -88,8 +88,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the MPC path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # under torch.distributed.run (RANK set) the RCCL group is created even for one rank, so that the same code path
+    # (init, barrier, all_reduce) runs at every N
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
@@ -98,7 +103,7 @@ def main():
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()                 # no-op when the in-tree libraries are current; only one rank may (re)build
-    if world > 1:
+    if distributed:
         dist.barrier()
 
     cfg = pkg.paper_config() if args.config == "paper" else pkg.horizon2x_config()
@@ -115,7 +120,7 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -136,7 +141,7 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     solved = torch.tensor([int((d_st == 1).sum().item())], dtype=torch.int64, device=dev)
     kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(solved, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
@@ -193,7 +198,7 @@ def main():
 
     barrier()
     mpc.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

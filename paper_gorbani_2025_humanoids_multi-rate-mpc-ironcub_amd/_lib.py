@@ -8,8 +8,7 @@ import os
 from .layout import CConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# VSMPC_LIB_PATH selects an alternative build of the same library (kernel experiments); default: the in-tree build
-LIB_PATH = os.environ.get("VSMPC_LIB_PATH") or os.path.join(HERE, "libvsmpc.so")
+LIB_PATH = os.path.join(HERE, "libvsmpc.so")
 
 # every symbol include/vsmpc.h declares
 EXPORTS = (
