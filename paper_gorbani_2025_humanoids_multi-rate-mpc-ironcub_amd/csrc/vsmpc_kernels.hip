@@ -293,14 +293,20 @@ VS_DEV void syrk_pass(d4 (&acc)[TPW], const double* const (&pa)[TPW], const doub
 // (LDS for the paper horizon, a global workspace for horizons whose factor does not fit LDS).
 // Returns non-zero if a pivot was not positive.
 // ------------------------------------------------------------------------------------------------
-template <class D, int NSLOT, int NPIV>
-VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane) {
+// SPLIT: the panel is shared by several wavefronts with no communication.  Each takes the diagonal tile in its lanes
+// 0..15 (factored redundantly, bit-identical everywhere) and 48 of the rows below it in lanes 16..63, so every
+// wavefront runs the short one-slot stream.  The other wavefronts read the unfactored diagonal tile while wavefront
+// w = 0 works, so in SPLIT mode the factored diagonal tile is not stored here: it is handed back in `diag` (lanes
+// 0..15 of wavefront 0) and stored by the caller after the workgroup barrier that ends the panel step.
+template <class D, int NSLOT, int NPIV, bool SPLIT = false>
+VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16]) {
+    static_assert(!SPLIT || NSLOT == 1, "split panels are one-slot");
     double* T[NSLOT];
     bool ok[NSLOT];
     double a[NSLOT][16];
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const int r = 16 * p + 64 * s + lane;
+        const int r = SPLIT ? (lane < 16 ? 16 * p + lane : 16 * p + 48 * w + lane) : 16 * p + 64 * s + lane;
         ok[s] = r < D::NP;
         T[s] = Lb + tile_off<D>(ok[s] ? (r >> 4) : p, p) + (r & 15) * 17;  // rows beyond the matrix read an
 #pragma unroll                                                              // in-range tile and are never stored
@@ -337,9 +343,13 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
             for (int s = 0; s < NSLOT; ++s) a[s][c] = fma(-l[s], lcj, a[s][c]);
         }
     }
-    if (ok[0]) {  // the part of the diagonal tile above the diagonal holds leftovers: its readers mask it
+    if (ok[0] && (!SPLIT || lane >= 16)) {  // above its diagonal the diagonal tile holds leftovers: readers mask it
 #pragma unroll
         for (int c = 0; c < 16; ++c) T[0][c] = a[0][c];
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) diag[c] = a[0][c];
     }
 #pragma unroll
     for (int s = 1; s < NSLOT; ++s)
@@ -347,7 +357,7 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll
             for (int c = 0; c < 16; ++c) T[s][c] = a[s][c];
         }
-    if (lane == 0) {
+    if (lane == 0 && (!SPLIT || w == 0)) {
 #pragma unroll
         for (int j = 0; j < NPIV; ++j) sInvD[16 * p + j] = invs[j];
     }
@@ -358,12 +368,13 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 template <class D>
 __device__ __attribute__((noinline)) int panel_factor_rt(double* Lb, double* sInvD, int p, int lane) {
     constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
-    if (p == D::NT - 1) return panel_factor<D, 1, NPIV_LAST>(Lb, sInvD, p, lane);
+    double unused[16];
+    if (p == D::NT - 1) return panel_factor<D, 1, NPIV_LAST>(Lb, sInvD, p, lane, 0, unused);
     const int rows = D::NP - 16 * p;
-    if (rows > 192) return panel_factor<D, 4, 16>(Lb, sInvD, p, lane);
-    if (rows > 128) return panel_factor<D, 3, 16>(Lb, sInvD, p, lane);
-    if (rows > 64) return panel_factor<D, 2, 16>(Lb, sInvD, p, lane);
-    return panel_factor<D, 1, 16>(Lb, sInvD, p, lane);
+    if (rows > 192) return panel_factor<D, 4, 16>(Lb, sInvD, p, lane, 0, unused);
+    if (rows > 128) return panel_factor<D, 3, 16>(Lb, sInvD, p, lane, 0, unused);
+    if (rows > 64) return panel_factor<D, 2, 16>(Lb, sInvD, p, lane, 0, unused);
+    return panel_factor<D, 1, 16>(Lb, sInvD, p, lane, 0, unused);
 }
 
 template <class D, int TPW, int NKS, int NACT = TPW>
@@ -455,22 +466,27 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < D::NT; ++p) {
-        if (W == 0) {
+        // rows under the diagonal tile and the wavefronts that share the panel (48 rows each, see panel_factor)
+        const int below = D::NP - 16 * p - 16;
+        const int nshare = D::L_IN_LDS ? (below <= 48 ? 1 : (below + 47) / 48) : 1;
+        double diag[16];  // factored diagonal tile of a shared panel (wavefront 0, lanes 0..15), stored after the barrier
+        if constexpr (D::L_IN_LDS) {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
-            int bad;
-            if constexpr (D::L_IN_LDS) {
-                if (p == D::NT - 1) bad = panel_factor<D, 1, NPIV_LAST>(sM, sInvD, p, lane);
-                else if (16 * p + 64 < D::NP) bad = panel_factor<D, 2, 16>(sM, sInvD, p, lane);
-                else bad = panel_factor<D, 1, 16>(sM, sInvD, p, lane);
-            } else {
-                bad = panel_factor_rt<D>(sM, sInvD, p, lane);
+            static_assert((D::NP - 16 + 47) / 48 <= D::NWAVES - 1, "panel 0 leaves one wavefront for the side work");
+            if (p == D::NT - 1) {
+                if (W == 0 && panel_factor<D, 1, NPIV_LAST>(sM, sInvD, p, lane, 0, diag) && lane == 0) sFlags[0] = 1;
+            } else if (W < nshare) {
+                const int bad = panel_factor<D, 1, 16, true>(sM, sInvD, p, lane, W, diag);
+                if (W == 0 && bad && lane == 0) sFlags[0] = 1;
             }
-            if (bad && lane == 0) sFlags[0] = 1;
+        } else if (W == 0) {
+            if (panel_factor_rt<D>(sM, sInvD, p, lane) && lane == 0) sFlags[0] = 1;
         }
         if constexpr (S::FASTSWEEP) {
-            // the other wavefronts idle while wavefront 0 factors panel p: wavefront 1 inverts the diagonal tile
-            // finished one panel ago, wavefronts 2 and 3 scale the tiles left of the one finished two panels ago
-            if (W == 1 && p >= 1 && p - 1 <= S::NJT)
+            // wavefronts without panel rows: one inverts the diagonal tile finished one panel ago (the last wavefront
+            // while wavefront 1 still has panel rows), wavefronts 2 and 3 scale the tiles left of the one finished two
+            // panels ago
+            if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p >= 1 && p - 1 <= S::NJT)
                 tile_inverse<D>(sM + tile_off<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
             if ((W == 2 || W == 3) && p >= 3 && p - 2 < S::NJT) {
                 const int pr = p - 2;
@@ -482,6 +498,13 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
         }
         if constexpr (!D::L_IN_LDS) __threadfence_block();  // panel lives in global memory: order it for the other waves
         __syncthreads();
+        if constexpr (D::L_IN_LDS) {
+            if (W == 0 && p < D::NT - 1 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
+                double* Tpp = sM + tile_off<D>(p, p) + lane * 17;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) Tpp[c] = diag[c];
+            }
+        }
         if constexpr (TPW > 12) {
             // long horizons (30 tiles per wavefront): tile by tile, operands straight from the (L2-resident) workspace
             if (p + 1 < D::NT) {
