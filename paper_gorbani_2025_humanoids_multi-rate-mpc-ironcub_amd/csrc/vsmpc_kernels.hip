@@ -47,15 +47,14 @@ VS_DEV double readlane_f64(double x, int lane) {
 }
 
 // 1/sqrt(d) and 1/d: hardware seed + refinement (full double precision to ~2 ulp)
-// The v_rsq_f64 / v_rcp_f64 seeds are good to 5e-8 (profiles/r01_microbench_rsq_accuracy.txt): two Newton steps
-// give full precision (2.4e-16), one leaves 4e-15.  A single cubically convergent (Halley) step is just as accurate
-// with a shorter dependent chain, but measured 3 k cycles SLOWER over the 120 Cholesky pivots (worse schedule).
+// The v_rsq_f64 / v_rcp_f64 seeds are good to 5e-8 (profiles/r01_microbench_rsq_accuracy.txt).  One cubically
+// convergent (Halley) step y (1 + e/2 + 3 e^2/8), e = 1 - d y^2, reaches full precision in 5 instructions; two Newton
+// steps need 7.  (With the pivots' reciprocal square roots on the critical path the Halley form measured slower; since
+// the panel code overlaps them with the previous pivot's update, the instruction count is what matters.)
 VS_DEV double fast_rsqrt(double d) {
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 VS_DEV double fast_rcp(double d) {
     double y = __builtin_amdgcn_rcp(d);
