@@ -363,19 +363,6 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
     return !(dmin > 0.0) || !(invs[NPIV - 1] == invs[NPIV - 1]);
 }
 
-// runtime-p wrapper (kept out of line for long horizons so that the unrolled panel loop stays small)
-template <class D>
-__device__ __attribute__((noinline)) int panel_factor_rt(double* Lb, double* sInvD, int p, int lane) {
-    constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
-    double unused[16];
-    if (p == D::NT - 1) return panel_factor<D, 1, NPIV_LAST>(Lb, sInvD, p, lane, 0, unused);
-    const int rows = D::NP - 16 * p;
-    if (rows > 192) return panel_factor<D, 4, 16>(Lb, sInvD, p, lane, 0, unused);
-    if (rows > 128) return panel_factor<D, 3, 16>(Lb, sInvD, p, lane, 0, unused);
-    if (rows > 64) return panel_factor<D, 2, 16>(Lb, sInvD, p, lane, 0, unused);
-    return panel_factor<D, 1, 16>(Lb, sInvD, p, lane, 0, unused);
-}
-
 template <class D, int TPW, int NKS, int NACT = TPW>
 VS_DEV void syrk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW],
                           int bufoff) {
@@ -467,9 +454,9 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
     for (int p = 0; p < D::NT; ++p) {
         // rows under the diagonal tile and the wavefronts that share the panel (48 rows each, see panel_factor)
         const int below = D::NP - 16 * p - 16;
-        const int nshare = D::L_IN_LDS ? (below <= 48 ? 1 : (below + 47) / 48) : 1;
+        const int nshare = below <= 48 ? 1 : (below + 47) / 48;
         double diag[16];  // factored diagonal tile of a shared panel (wavefront 0, lanes 0..15), stored after the barrier
-        if constexpr (D::L_IN_LDS) {
+        {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
             static_assert((D::NP - 16 + 47) / 48 <= D::NWAVES - 1, "panel 0 leaves one wavefront for the side work");
             if (p == D::NT - 1) {
@@ -478,8 +465,6 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
                 const int bad = panel_factor<D, 1, 16, true>(sM, sInvD, p, lane, W, diag);
                 if (W == 0 && bad && lane == 0) sFlags[0] = 1;
             }
-        } else if (W == 0) {
-            if (panel_factor_rt<D>(sM, sInvD, p, lane) && lane == 0) sFlags[0] = 1;
         }
         if constexpr (S::FASTSWEEP) {
             // wavefronts without panel rows: one inverts the diagonal tile finished one panel ago (the last wavefront
@@ -497,7 +482,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
         }
         if constexpr (!D::L_IN_LDS) __threadfence_block();  // panel lives in global memory: order it for the other waves
         __syncthreads();
-        if constexpr (D::L_IN_LDS) {
+        {
             if (W == 0 && p < D::NT - 1 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
                 double* Tpp = sM + tile_off<D>(p, p) + lane * 17;
 #pragma unroll
