@@ -551,7 +551,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K x K symmetric positive definite system P_AA mu = rhs_A of the dual box QP, K <= 4, all lanes redundantly on
+// K x K symmetric positive definite system (P_AA mu = rhs_A of the dual box QP, S_FF v_F = b_F of the primal), K <= 12, all lanes redundantly on
 // wave-uniform values (symmetric elimination on the lower triangle).  sP[b * NVS + i] = P[i][b]; the K set bits of
 // `mask` are the active indices; lane idx[q] returns mu_q, every other lane 0.
 template <int K, int NVS>
@@ -592,6 +592,18 @@ VS_DEV double small_spd_solve(const double* __restrict__ sP, unsigned long long 
         mu = (lane == idx[j]) ? x[j] : mu;
     }
     return mu;
+}
+
+// size dispatch for small_spd_solve (one straight-line instantiation per size)
+constexpr int SMALL_SOLVE_MAX = 12;
+template <int NVS, int K = SMALL_SOLVE_MAX>
+VS_DEV double small_spd_solve_n(int k, const double* __restrict__ sP, unsigned long long mask, double rhs, int lane, int& bad) {
+    if constexpr (K == 1) {
+        return small_spd_solve<1, NVS>(sP, mask, rhs, lane, bad);
+    } else {
+        if (k == K) return small_spd_solve<K, NVS>(sP, mask, rhs, lane, bad);
+        return small_spd_solve_n<NVS, K - 1>(k, sP, mask, rhs, lane, bad);
+    }
 }
 
 // s = L22 (L^-1 g)_v, whose largest entry scales the release tolerance of the box QP (row NZ of the factor holds L^-1 g)
@@ -1113,8 +1125,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     VS_STAMP(5);
 
     // few saturated throttles (the usual case): dual form, cost grows with the number of active bounds;
-    // many: primal form on the Schur complement, cost independent of it
-    constexpr int DUAL_MAX_ACTIVE = 4;
+    // many: primal form on the Schur complement, cost grows with the number of free throttles
+    constexpr int DUAL_MAX_ACTIVE = 10;
     const bool use_dual = DUALQP && sFlags[3] <= DUAL_MAX_ACTIVE;
     if (need_qp) {
       if (use_dual) {
@@ -1236,14 +1248,9 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
                 double mu = 0.0;
                 const int ka = __popcll(Amask);
-                if (ka <= 4) {
-                    // up to four active bounds: solved redundantly in every lane on wave-uniform values
-                    switch (ka) {
-                        case 1: mu = small_spd_solve<1, D::NV + 1>(sP, Amask, bb, lane, bad); break;
-                        case 2: mu = small_spd_solve<2, D::NV + 1>(sP, Amask, bb, lane, bad); break;
-                        case 3: mu = small_spd_solve<3, D::NV + 1>(sP, Amask, bb, lane, bad); break;
-                        default: mu = small_spd_solve<4, D::NV + 1>(sP, Amask, bb, lane, bad); break;
-                    }
+                if (ka <= SMALL_SOLVE_MAX) {
+                    // few active bounds: solved redundantly in every lane on wave-uniform values
+                    mu = small_spd_solve_n<D::NV + 1>(ka, sP, Amask, bb, lane, bad);
                 } else {
                     // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
                     if (isA) {
@@ -1368,26 +1375,41 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                     if (isF && !cF) b -= row[c] * vbc;
                     a[c] = (isF && cF) ? row[c] : ((c == r && !isF) ? 1.0 : 0.0);
                 }
-                // Gaussian elimination without pivoting (SPD), pivot rows broadcast with v_readlane
                 int bad = 0;
+                const int nfree = __popcll(Fmask);
+                if (nfree >= 1 && nfree <= SMALL_SOLVE_MAX) {
+                    // deep saturation leaves few free throttles: S_FF v_F = b_F redundantly in registers on
+                    // wave-uniform values (S is symmetric: sSv[c * (NV+1) + i] = S[i][c], the layout the solver reads)
+                    const double vf = small_spd_solve_n<D::NV + 1>(nfree, sSv, Fmask, b, lane, bad);
+                    v = isF ? vf : vb;
+                } else {
+                // Gaussian elimination without pivoting (SPD), pivot rows broadcast with v_readlane.  Rows of bound
+                // throttles are identity rows whose column is zero elsewhere: their pivots are no-ops and are skipped
+                // (wave-uniform branch), so the cost follows the number of free throttles
 #pragma unroll
                 for (int j = 0; j < D::NV; ++j) {
-                    const double piv = readlane_f64(a[j], j);
-                    bad |= !(piv > 0.0);
-                    const double f = (lane > j) ? a[j] * fast_rcp(piv) : 0.0;
-                    const double bj = readlane_f64(b, j);
-                    b -= f * bj;
+                    if ((Fmask >> j) & 1ull) {
+                        const double piv = readlane_f64(a[j], j);
+                        bad |= !(piv > 0.0);
+                        const double f = (lane > j) ? a[j] * fast_rcp(piv) : 0.0;
+                        const double bj = readlane_f64(b, j);
+                        b -= f * bj;
 #pragma unroll
-                    for (int c = j + 1; c < D::NV; ++c) {
-                        const double pc = readlane_f64(a[c], j);
-                        a[c] -= f * pc;
+                        for (int c = j + 1; c < D::NV; ++c) {
+                            const double pc = readlane_f64(a[c], j);
+                            a[c] -= f * pc;
+                        }
                     }
                 }
+                v = vb;  // bound throttles; free ones follow from the back-substitution
 #pragma unroll
                 for (int j = D::NV - 1; j >= 0; --j) {
-                    const double xj = readlane_f64(b, j) * fast_rcp(readlane_f64(a[j], j));
-                    if (lane == j) v = xj;
-                    if (lane < j) b -= a[j] * xj;
+                    if ((Fmask >> j) & 1ull) {
+                        const double xj = readlane_f64(b, j) * fast_rcp(readlane_f64(a[j], j));
+                        if (lane == j) v = xj;
+                        if (lane < j) b -= a[j] * xj;
+                    }
+                }
                 }
                 if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
                 double grad = svr;
