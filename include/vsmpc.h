@@ -233,12 +233,14 @@ typedef struct vsmpc_rollout vsmpc_rollout;
 int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, const double* traj_vel, int n_traj,
                          const double* traj_alpha, int n_alpha, double alpha_dt, vsmpc_rollout** out);
 void vsmpc_rollout_destroy(vsmpc_rollout* r);
-/* Host -> device: state[batch][VSMPC_PLANT_STATE], params[batch][VSMPC_PLANT_PARAMS]; resets the tick counters. */
+/* Host -> device: state[batch][VSMPC_PLANT_STATE], params[batch][VSMPC_PLANT_PARAMS]; resets the tick counters and
+ * builds the record of tick 0 on the device. */
 int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* params);
 /* Runs `ticks` closed-loop ticks on `stream`; log (host, may be NULL) receives [ticks][batch][VSMPC_ROLLOUT_LOG].
  * Returns after the last tick has completed. */
 int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream);
-/* Device -> host copies of the current plant state / the records of the LAST tick ([batch][n_in], parity hook). */
+/* Device -> host copies of the current plant state / of the records the NEXT tick will solve ([batch][n_in], parity
+ * hook: after reset the records of tick 0, after run(k) those of tick k). */
 int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state);
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
 

@@ -44,6 +44,7 @@ struct vsmpc_rollout {
     double* d_talpha;
     double* d_log;
     int log_ticks;
+    double* d_rec;            // record of the next tick ([batch][n_in]): written by reset and by every tick's advance
     RolloutCtl* d_ctl;        // per-run control block read by advance_kernel (log destination, tick base)
     int ticks_done;           // ticks since the last reset (the same for every instance)
     hipStream_t own_stream;   // used when the caller passes the null stream (which cannot be captured)
@@ -427,7 +428,7 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
     r->rd.n_alpha = n_alpha;
     r->rd.period_mpc = h->cfg.period_mpc;
     r->rd.alpha_dt = alpha_dt;
-    r->substeps = std::max(1, int(std::lround(h->cfg.period_mpc / 1e-3)));      // 1 kHz plant, as the MuJoCo harness
+    r->substeps = std::min(16, std::max(1, int(std::lround(h->cfg.period_mpc / 1e-3))));  // 1 kHz plant, as the MuJoCo harness
     const size_t B = size_t(batch);
     hipError_t e = hipMalloc(&r->d_state, B * VSMPC_PLANT_STATE * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&r->d_params, B * VSMPC_PLANT_PARAMS * sizeof(double));
@@ -440,6 +441,8 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
     if (e == hipSuccess) e = hipMemcpy(r->d_talpha, traj_alpha, size_t(n_alpha) * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(r->d_tick, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&r->d_ctl, sizeof(RolloutCtl));
+    if (e == hipSuccess) e = hipMalloc(&r->d_rec, B * h->n_in * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(r->d_rec, 0, B * h->n_in * sizeof(double));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         vsmpc_rollout_destroy(r);
@@ -460,6 +463,7 @@ void vsmpc_rollout_destroy(vsmpc_rollout* r) {
     if (r->d_talpha) (void)hipFree(r->d_talpha);
     if (r->d_log) (void)hipFree(r->d_log);
     if (r->d_ctl) (void)hipFree(r->d_ctl);
+    if (r->d_rec) (void)hipFree(r->d_rec);
     if (r->gexec) (void)hipGraphExecDestroy(r->gexec);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
@@ -473,6 +477,10 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
     HIP_TRY(hipMemcpy(r->d_params, params, B * VSMPC_PLANT_PARAMS * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(r->d_tick, 0, B * sizeof(int)));
     r->ticks_done = 0;
+    // record of tick 0; from here on every tick's advance kernel leaves the record of the following tick
+    HIP_TRY(launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha, r->d_rec,
+                          nullptr));
+    HIP_TRY(hipDeviceSynchronize());
     return VSMPC_OK;
 }
 
@@ -480,24 +488,22 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
 
 namespace {
 
-constexpr int GRAPH_TICKS = 25;  // ticks per captured graph (75 kernel nodes)
+constexpr int GRAPH_TICKS = 25;  // ticks per captured graph (50 kernel nodes)
 
-// one closed-loop tick: three launches on `s`, the stream order is the only synchronisation the loop needs
+// one closed-loop tick: two launches on `s` (solve, advance + next record), the stream order is the only
+// synchronisation the loop needs
 hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
     vsmpc_handle* h = r->h;
-    hipError_t e = launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha,
-                                 h->d_in, s);
-    if (e == hipSuccess)
-        e = launch_solve(h->variant, h->dev, h->d_in, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr, nullptr,
-                         nullptr, h->d_ws, s);
+    hipError_t e = launch_solve(h->variant, h->dev, r->d_rec, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+                                nullptr, nullptr, h->d_ws, s);
     if (e == hipSuccess)
         e = launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
-                           r->d_talpha, r->d_ctl, r->substeps, s);
+                           r->d_talpha, r->d_ctl, r->substeps, r->d_tpos, r->d_tvel, r->d_rec, s);
     return e;
 }
 
 // Captures GRAPH_TICKS ticks into a graph (every launch argument is tick-invariant: tick counters, log destination and
-// tick base live in device memory).  Launch-bound loop -> one graph launch per chunk instead of 75 kernel launches.
+// tick base live in device memory).  Launch-bound loop -> one graph launch per chunk instead of 50 kernel launches.
 void build_tick_graph(vsmpc_rollout* r, hipStream_t s) {
     r->graph_state = -1;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -556,7 +562,7 @@ int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state) {
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records) {
     if (r == nullptr || records == nullptr) return VSMPC_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(r->h->device));
-    HIP_TRY(hipMemcpy(records, r->h->d_in, size_t(r->batch) * r->h->n_in * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(records, r->d_rec, size_t(r->batch) * r->h->n_in * sizeof(double), hipMemcpyDeviceToHost));
     return VSMPC_OK;
 }
 

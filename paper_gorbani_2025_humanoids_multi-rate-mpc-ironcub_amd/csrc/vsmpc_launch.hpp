@@ -37,6 +37,6 @@ hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, c
                          hipStream_t stream);
 hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
                           const int* status, const int* iters, const double* traj_alpha, const RolloutCtl* ctl, int substeps,
-                          hipStream_t stream);
+                          const double* traj_pos, const double* traj_vel, double* rec_next, hipStream_t stream);
 
 }  // namespace vsmpc

@@ -52,22 +52,30 @@ VS_DEV double interp_clamped(const double* __restrict__ tr, int n, double pos) {
 // is assembled in LDS by all 64 lanes (every field is a short independent expression) and written out coalesced.
 constexpr int RO_BLOCK = 64;
 
-VS_DEV void stage_in(const double* __restrict__ g, double* __restrict__ l, int n, int lane) {
-    for (int i = lane; i < n; i += RO_BLOCK) l[i] = g[i];
+// global -> LDS staging with all loads in flight before the first store (a load/store loop pays one HBM round trip
+// per iteration)
+template <int N>
+VS_DEV void stage_in(const double* __restrict__ g, double* __restrict__ l, int lane) {
+    constexpr int R = (N + RO_BLOCK - 1) / RO_BLOCK;
+    double v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = lane + k * RO_BLOCK;
+        v[k] = i < N ? g[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int i = lane + k * RO_BLOCK;
+        if (i < N) l[i] = v[k];
+    }
 }
 
-__global__ __launch_bounds__(RO_BLOCK) void record_kernel(RolloutDev rd, int batch, const double* __restrict__ state,
-                                                           const double* __restrict__ params, const int* __restrict__ tick,
-                                                           const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
-                                                           const double* __restrict__ traj_alpha, double* __restrict__ rec) {
-    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], R[9], om[3];
-    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= batch) return;
-    stage_in(state + size_t(b) * VSMPC_PLANT_STATE, s, VSMPC_PLANT_STATE, lane);
-    stage_in(params + size_t(b) * VSMPC_PLANT_PARAMS, p, VSMPC_PLANT_PARAMS, lane);
-    __syncthreads();
-    const int tk = tick[b] + int(p[VSMPC_PP_TICK0]);
+// Record of tick `tk` from the plant state `s` and parameters `p` (both in LDS), assembled into `r` (LDS) by the 64
+// lanes of the workgroup.  Ends with a barrier: `r` is complete on return.
+VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, const double* __restrict__ p, int tk,
+                            const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
+                            const double* __restrict__ traj_alpha, double* __restrict__ R, double* __restrict__ om,
+                            double* __restrict__ r, int lane) {
     const double m = p[VSMPC_PP_MASS];
     if (lane == 0) {
         rot_from_rpy(s + VSMPC_PS_RPY, R);
@@ -149,26 +157,53 @@ __global__ __launch_bounds__(RO_BLOCK) void record_kernel(RolloutDev rd, int bat
         r[VSMPC_IN_PREF + lane] = r[VSMPC_IN_XREF + lane];
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(RO_BLOCK) void record_kernel(RolloutDev rd, int batch, const double* __restrict__ state,
+                                                           const double* __restrict__ params, const int* __restrict__ tick,
+                                                           const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
+                                                           const double* __restrict__ traj_alpha, double* __restrict__ rec) {
+    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], R[9], om[3];
+    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= batch) return;
+    stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
+    stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
+    __syncthreads();
+    assemble_record(rd, s, p, tick[b] + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, r, lane);
     double* out = rec + size_t(b) * rd.n_in;
     for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
 }
 
 // One wavefront per instance: staging and the joint-dependent jet map in parallel, the short ODE integration in lane 0
-// on registers, coalesced write-back.
+// on registers, coalesced write-back.  With `rec_next` the record of the NEXT tick is assembled from the advanced state
+// while it is still in LDS (one launch and one staging less per tick than a separate record_kernel).
 __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int batch, double* __restrict__ state,
                                                             const double* __restrict__ params, int* __restrict__ tick,
                                                             const double* __restrict__ fm, const int* __restrict__ status,
                                                             const int* __restrict__ iters, const double* __restrict__ traj_alpha,
-                                                            const RolloutCtl* __restrict__ ctl, int substeps) {
-    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9];
+                                                            const RolloutCtl* __restrict__ ctl, int substeps,
+                                                            const double* __restrict__ traj_pos,
+                                                            const double* __restrict__ traj_vel, double* __restrict__ rec_next) {
+    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9], R[9], om[3];
+    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
-    stage_in(state + size_t(b) * VSMPC_PLANT_STATE, s, VSMPC_PLANT_STATE, lane);
-    stage_in(params + size_t(b) * VSMPC_PLANT_PARAMS, p, VSMPC_PLANT_PARAMS, lane);
-    stage_in(fm + size_t(b) * VSMPC_FM_SIZE, f, VSMPC_FM_SIZE, lane);
+    stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
+    stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
+    stage_in<VSMPC_FM_SIZE>(fm + size_t(b) * VSMPC_FM_SIZE, f, lane);
     const int st = status[b];
     const int tick_before = tick[b];
+    // every global load of this kernel is requested as early as possible: each dependent round trip costs ~1.5 us
+    double* const log = ctl->log;
+    const int tick_base = ctl->tick_base;
     __syncthreads();
+    __shared__ double alpha_s[16];   // alpha-gravity of every sub-step (one round trip instead of one per sub-step)
+    if (lane >= 32 && lane < 32 + substeps && lane < 48) {
+        const int ss = lane - 32;
+        const double t = (double(tick_before + int(p[VSMPC_PP_TICK0])) + double(ss) / double(substeps)) * rd.period_mpc;
+        alpha_s[ss] = interp_clamped(traj_alpha, rd.n_alpha, t / rd.alpha_dt);
+    }
     if (st == VSMPC_STATUS_SOLVED) {  // variableSamplingMPC.cpp:91-108
         if (lane < 8) s[VSMPC_PS_Q + lane] += f[VSMPC_FM_DQ + lane];
         if (lane >= 8 && lane < 12) {
@@ -187,62 +222,78 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
         inv3(p + VSMPC_PP_INERTIA_B, IBi);
     }
     __syncthreads();
-    if (lane == 0) {
+    // explicit Euler sub-steps, one state component per lane (20 lanes): the three sincos run side by side in lanes
+    // 0..2, the body rates in lanes 8..10, then every lane forms the derivative of its own component
+    {
+        __shared__ double x[20], Rm[9], omv[3], sc[6], vthr[4];
         const int tk = tick_before + int(p[VSMPC_PP_TICK0]);
         const double m = p[VSMPC_PP_MASS];
-        double x[20], A[24], Ii[9], vthr[4];
-        for (int i = 0; i < 20; ++i) x[i] = s[i];
-        for (int i = 0; i < 24; ++i) A[i] = Aq[i];
-        for (int i = 0; i < 9; ++i) Ii[i] = IBi[i];
-        for (int i = 0; i < 4; ++i) vthr[i] = Jet::v_of_throttle(s[VSMPC_PS_U + i]);
+        if (lane < 20) x[lane] = s[lane];
+        if (lane < 4) vthr[lane] = Jet::v_of_throttle(s[VSMPC_PS_U + lane]);
+        __syncthreads();
         const double h = rd.period_mpc / double(substeps);
         for (int ss = 0; ss < substeps; ++ss) {
             const double t = (double(tk) + double(ss) / double(substeps)) * rd.period_mpc;
-            const double alpha = interp_clamped(traj_alpha, rd.n_alpha, t / rd.alpha_dt);
+            const double alpha = alpha_s[ss];
             const bool dist = t >= p[VSMPC_PP_DIST_T0] && t < p[VSMPC_PP_DIST_T1];
-            double sr, cr, sp, cp, sy, cy;
-            sincos(x[6], &sr, &cr); sincos(x[7], &sp, &cp); sincos(x[8], &sy, &cy);
-            const double R[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
-                                 sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
-                                 -sp,     cp * sr,                cp * cr};
-            double om[3], d[20];
-            for (int i = 0; i < 3; ++i) om[i] = Ii[3 * i] * x[9] + Ii[3 * i + 1] * x[10] + Ii[3 * i + 2] * x[11];
-            for (int i = 0; i < 3; ++i) d[i] = (R[3 * i] * x[3] + R[3 * i + 1] * x[4] + R[3 * i + 2] * x[5]) / m;     // p' = R h_lin / m
-            const double cl[3] = {om[1] * x[5] - om[2] * x[4], om[2] * x[3] - om[0] * x[5], om[0] * x[4] - om[1] * x[3]};   // omega x h_lin
-            const double ca[3] = {om[1] * x[11] - om[2] * x[10], om[2] * x[9] - om[0] * x[11], om[0] * x[10] - om[1] * x[9]};
-            for (int r = 0; r < 3; ++r) {
-                double fl = -cl[r] + alpha * m * (R[6 + r] * (-9.81));     // alpha m R^T g, g = (0,0,-9.81)
-                double fa = -ca[r];
-                for (int j = 0; j < 4; ++j) { fl += A[4 * r + j] * x[12 + j]; fa += A[4 * (3 + r) + j] * x[12 + j]; }
-                if (dist) {
-                    fl += R[r] * p[VSMPC_PP_DIST_F] + R[3 + r] * p[VSMPC_PP_DIST_F + 1] + R[6 + r] * p[VSMPC_PP_DIST_F + 2];
-                    fa += p[VSMPC_PP_DIST_TAU + r];
-                }
-                d[3 + r] = fl;
-                d[9 + r] = fa;
+            if (lane < 3) {
+                double sn, cs;
+                sincos(x[6 + lane], &sn, &cs);
+                sc[2 * lane] = sn;
+                sc[2 * lane + 1] = cs;
+            } else if (lane >= 8 && lane < 11) {
+                const int i = lane - 8;
+                omv[i] = IBi[3 * i] * x[9] + IBi[3 * i + 1] * x[10] + IBi[3 * i + 2] * x[11];
             }
-            const double tp = sp / cp;
-            d[6] = om[0] + sr * tp * om[1] + cr * tp * om[2];      // rpy' = W^-1 omega (systemDynamicsVSMPC.cpp:140-147)
-            d[7] = cr * om[1] - sr * om[2];
-            d[8] = (sr * om[1] + cr * om[2]) / cp;
-            for (int i = 0; i < 4; ++i) {                           // T'' = sigma_T (f + g v(u))  (JetModel.cpp:29-64)
-                const double Tb = Jet::stdT(x[12 + i]), Tdb = Jet::stdTd(x[16 + i]);
-                d[12 + i] = x[16 + i];
-                d[16 + i] = Jet::sgT * (Jet::f(Tb, Tdb) + Jet::g(Tb, Tdb) * vthr[i]);
+            __syncthreads();
+            const double sr = sc[0], cr = sc[1], sp = sc[2], cp = sc[3], sy = sc[4], cy = sc[5];
+            if (lane == 0) {
+                Rm[0] = cy * cp; Rm[1] = cy * sp * sr - sy * cr; Rm[2] = cy * sp * cr + sy * sr;
+                Rm[3] = sy * cp; Rm[4] = sy * sp * sr + cy * cr; Rm[5] = sy * sp * cr - cy * sr;
+                Rm[6] = -sp;     Rm[7] = cp * sr;                Rm[8] = cp * cr;
             }
-            for (int i = 0; i < 20; ++i) x[i] += h * d[i];
+            __syncthreads();
+            double d = 0.0;
+            if (lane < 3) {                                   // p' = R h_lin / m
+                d = (Rm[3 * lane] * x[3] + Rm[3 * lane + 1] * x[4] + Rm[3 * lane + 2] * x[5]) / m;
+            } else if (lane < 6 || (lane >= 9 && lane < 12)) { // momentum rates: -omega x h + A_mom(q) T (+ gravity, push)
+                const bool lin = lane < 6;
+                const int r = lin ? lane - 3 : lane - 9, h0 = lin ? 3 : 9;
+                const int r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+                const double cross = omv[r1] * x[h0 + r2] - omv[r2] * x[h0 + r1];   // (omega x h)[r]
+                double f = -cross;
+                if (lin) f += alpha * m * (Rm[6 + r] * (-9.81));                    // alpha m R^T g, g = (0,0,-9.81)
+                for (int j = 0; j < 4; ++j) f += Aq[4 * (lin ? r : 3 + r) + j] * x[12 + j];
+                if (dist)
+                    f += lin ? Rm[r] * p[VSMPC_PP_DIST_F] + Rm[3 + r] * p[VSMPC_PP_DIST_F + 1] + Rm[6 + r] * p[VSMPC_PP_DIST_F + 2]
+                             : p[VSMPC_PP_DIST_TAU + r];
+                d = f;
+            } else if (lane < 9) {                            // rpy' = W^-1 omega (systemDynamicsVSMPC.cpp:140-147)
+                const double tp = sp / cp;
+                d = lane == 6 ? omv[0] + sr * tp * omv[1] + cr * tp * omv[2]
+                  : lane == 7 ? cr * omv[1] - sr * omv[2]
+                              : (sr * omv[1] + cr * omv[2]) / cp;
+            } else if (lane < 16) {                           // T' = Tdot
+                d = x[lane + 4];
+            } else if (lane < 20) {                           // T'' = sigma_T (f + g v(u))  (JetModel.cpp:29-64)
+                const int j = lane - 16;
+                const double Tb = Jet::stdT(x[12 + j]), Tdb = Jet::stdTd(x[16 + j]);
+                d = Jet::sgT * (Jet::f(Tb, Tdb) + Jet::g(Tb, Tdb) * vthr[j]);
+            }
+            __syncthreads();                                  // every lane has read x before anyone updates it
+            if (lane < 20) x[lane] += h * d;
+            __syncthreads();
         }
-        for (int i = 0; i < 20; ++i) s[i] = x[i];
-        tick[b] = tick_before + 1;
+        if (lane < 20) s[lane] = x[lane];
+        if (lane == 0) tick[b] = tick_before + 1;
     }
     __syncthreads();
     double* so = state + size_t(b) * VSMPC_PLANT_STATE;
     for (int i = lane; i < VSMPC_PLANT_STATE; i += RO_BLOCK) so[i] = s[i];
     // the log destination comes from a device-side control block, so the launch arguments are the same for every
     // tick and a captured graph of ticks can be replayed
-    double* log = ctl->log;
     if (log != nullptr && lane < VSMPC_ROLLOUT_LOG) {
-        const int row = tick_before - ctl->tick_base;   // ticks since the start of this run
+        const int row = tick_before - tick_base;   // ticks since the start of this run
         double v;
         if (lane < 3) v = s[lane];
         else if (lane < 6) v = s[6 + lane - 3];
@@ -251,6 +302,11 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
         else if (lane == 14) v = double(st);
         else v = iters ? double(iters[b]) : 0.0;
         log[(size_t(row) * batch + b) * VSMPC_ROLLOUT_LOG + lane] = v;
+    }
+    if (rec_next != nullptr) {
+        assemble_record(rd, s, p, tick_before + 1 + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, r, lane);
+        double* out = rec_next + size_t(b) * rd.n_in;
+        for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
     }
 }
 
@@ -264,9 +320,9 @@ hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, c
 
 hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
                           const int* status, const int* iters, const double* traj_alpha, const RolloutCtl* ctl, int substeps,
-                          hipStream_t stream) {
+                          const double* traj_pos, const double* traj_vel, double* rec_next, hipStream_t stream) {
     hipLaunchKernelGGL(advance_kernel, dim3(batch), dim3(RO_BLOCK), 0, stream, rd, batch, state, params, tick, fm,
-                       status, iters, traj_alpha, ctl, substeps);
+                       status, iters, traj_alpha, ctl, substeps, traj_pos, traj_vel, rec_next);
     return hipGetLastError();
 }
 

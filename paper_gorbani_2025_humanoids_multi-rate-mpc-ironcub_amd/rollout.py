@@ -174,7 +174,8 @@ class ClosedLoopRollout:
         _lib.check(self.lib.vsmpc_rollout_get_state(self._r, _ptr(out)), "vsmpc_rollout_get_state")
         return out
 
-    def last_records(self) -> np.ndarray:
+    def next_records(self) -> np.ndarray:
+        """Records the next tick will solve (after reset: tick 0; after run(k): tick k)."""
         out = np.empty((self.batch, self.cfg.n_in))
         _lib.check(self.lib.vsmpc_rollout_get_records(self._r, _ptr(out)), "vsmpc_rollout_get_records")
         return out

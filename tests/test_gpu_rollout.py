@@ -31,10 +31,9 @@ def test_record_and_advance_kernels_match_model(ro, layout, workload):
     cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, workload)
     try:
         s_host = st.copy()
+        recs = r.next_records()                                # record of tick 0, built on the device by reset()
         for tick in range(3):
             log = r.run(1)
-            recs = r.last_records()
-            fm, status = None, None
             x, fm, status, iters = r.mpc.solve(recs)          # same kernel, same records -> the first move the loop used
             after = r.state()
             for b in range(B):
@@ -44,6 +43,7 @@ def test_record_and_advance_kernels_match_model(ro, layout, workload):
                 assert relerr(after[b], s_m) < 1e-12, (workload, tick, b)
                 assert log[0, b, 14] == status[b] and log[0, b, 15] == iters[b]
                 np.testing.assert_allclose(log[0, b, 0:3], after[b, 0:3], rtol=0, atol=0)
+            recs = r.next_records()                            # assembled by the advance kernel from the new state
             s_host = after
     finally:
         r.close()
