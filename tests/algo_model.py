@@ -12,7 +12,9 @@ Phases (same names as the kernel):
                     column order: [U_0..U_{H-1} | v_1..v_{nvb-1} | v_0 | affine | pad]
   P2 augment        M = C + R ; row `NZ` of M holds the condensed gradient
   P3 cholesky       first NZ pivots of the padded matrix; row NZ becomes (L^-1 g)^T
-  P4 box QP on v    S = L22 L22^T, s = L22 (L^-1 g)_v ; block principal pivoting
+  P4 box QP on v    S = L22 L22^T, s = L22 (L^-1 g)_v ; block principal pivoting, in the primal form (masked
+                    system on S) or, `dual=True`, in the dual form on P = S_NN^-1 = X^T X the kernel uses for few
+                    active bounds; both produce the same iterate for a given active set
   P5 back-subst     U = L11^-T (y_U - L21^T v)
   P6 simulate       X_{k+1} = X_k + dt_k (A X_k + Bj U + Bt v + c)
 """
@@ -32,7 +34,7 @@ def column_maps(cfg):
     return cols
 
 
-def solve_model(cfg, oracle, inp, max_bpp_iter=60):
+def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None):
     """`oracle` is the oracle module (for linearize/dt_schedule helpers that restate the reference);
     everything downstream of (A, Bj, Bt, c) is the kernel's own algorithm."""
     N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
@@ -125,15 +127,36 @@ def solve_model(cfg, oracle, inp, max_bpp_iter=60):
     state[fixed] = -1
     v = np.zeros(NV)
     best, patience, status, iters = NV + 1, 3, 2, 0
+    # dual form (what the kernel runs for few active bounds): N = throttles not pinned by the hold, X = L_N^-1 with L_N
+    # the leading block of L22 (= the factor of S_NN), P = S_NN^-1 = X^T X, v_u = the solve with only the pins enforced.
+    # Fixing A at its bounds b_A:  mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.
+    n_free = NV - 4 if hold else NV
+    Xn = np.linalg.inv(L22[:n_free, :n_free])
+    P = Xn.T @ Xn
+    pinned = np.where(fixed, lo, 0.0)
+    vu = np.linalg.solve(Sv[:n_free, :n_free], -(sv[:n_free] + Sv[:n_free, n_free:] @ pinned[n_free:]))
     for it in range(max_bpp_iter):
         iters = it + 1
         F = state == 0
         v = np.where(state == -1, lo, np.where(state == 1, hi, 0.0))
-        # masked system: identity on bound rows (what the single-wave kernel factorises)
-        Sm = np.where(np.outer(F, F), Sv, 0.0) + np.diag((~F).astype(float))
-        rhs = np.where(F, -(sv + Sv @ np.where(F, 0.0, v)), v)
-        v = np.linalg.solve(Sm, rhs)
-        grad = Sv @ v + sv
+        if dual:
+            A_ = np.nonzero((state != 0) & ~fixed)[0]
+            vN = vu.copy()
+            grad = np.zeros(NV)
+            if A_.size:
+                mu = np.linalg.solve(P[np.ix_(A_, A_)], vu[A_] - v[A_])
+                vN = vu - P[:, A_] @ mu
+                vN[A_] = v[A_]                      # bound variables sit exactly on their bound
+                grad[A_] = -mu
+            v = np.concatenate([vN, v[n_free:]])
+        else:
+            # masked system: identity on bound rows (what the single-wave kernel factorises)
+            Sm = np.where(np.outer(F, F), Sv, 0.0) + np.diag((~F).astype(float))
+            rhs = np.where(F, -(sv + Sv @ np.where(F, 0.0, v)), v)
+            v = np.linalg.solve(Sm, rhs)
+            grad = Sv @ v + sv
+        if trace is not None:
+            trace.append((state.copy(), v.copy(), np.where((state != 0) & ~fixed, grad, 0.0)))
         tolv = 1e-12 * (1.0 + np.abs(v))
         gtol = 1e-10 * (1.0 + np.abs(sv).max())
         vlo = F & (v < lo - tolv)

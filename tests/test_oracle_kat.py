@@ -159,6 +159,32 @@ def test_algorithm_model_matches_oracle(ref, golden_paper, golden_h2x, which):
         assert iters == int(gold["iters"][i])
 
 
+def test_dual_and_primal_box_qp_iterates_agree(ref, synth, layout):
+    """The dual form of the box QP (P = S_NN^-1 = X^T X, mu = P_AA^-1 (v_u,A - b_A)) that the kernel runs for few
+    active bounds walks through the same active sets, throttles and multipliers as the primal form on the Schur
+    complement, iteration by iteration, and ends at the oracle's optimum."""
+    import algo_model
+    cfg, rcfg = layout.paper_config(), ref.paper_config()
+    recs = np.concatenate([synth.make_batch(cfg, 48, workload="takeoff", seed0=9000),
+                           synth.make_batch(cfg, 48, workload="montecarlo", seed0=9500)])
+    multi = 0
+    for rec in recs:
+        tp, td = [], []
+        xp, sp_, itp = algo_model.solve_model(rcfg, ref, rec, trace=tp)
+        xd, sd_, itd = algo_model.solve_model(rcfg, ref, rec, dual=True, trace=td)
+        assert sp_ == sd_ == 1 and itp == itd
+        for (s1, v1, g1), (s2, v2, g2) in zip(tp, td):
+            np.testing.assert_array_equal(s1, s2)
+            np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(g1, g2, rtol=0, atol=1e-7 * (1.0 + np.abs(g1).max()))
+        np.testing.assert_allclose(xp, xd, rtol=0, atol=1e-9)
+        if itp > 1:
+            multi += 1
+            xo, _, ito, _ = ref.solve_instance(rcfg, rec)
+            assert ito == itp and np.abs(xd - xo).max() / max(1.0, np.abs(xo).max()) < 1e-10
+    assert multi >= 5
+
+
 def test_kinematics_terms_closed_form(ref):
     """Single jet, identity attitude: Lambda_lin = -T S(a) J_rel, Lambda_ang = -T (S(a)(J_f - J_c) + S(r) S(a) J_rel),
     I_G = parallel-axis form of the base block (systemDynamicsVSMPC.cpp:128-130,159-226,321-350)."""
