@@ -59,6 +59,15 @@ def test_strerror_and_arg_validation_without_gpu(solver_mod, pkg, layout):
     assert lib.vsmpc_create(None, 0, 4, ctypes.byref(h)) == -1
     assert lib.vsmpc_num_variables(None) == -1
     lib.vsmpc_destroy(None)                                                            # must be a no-op
+    # rollout entry points validate their arguments before touching the device
+    r = ctypes.c_void_p()
+    z = np.zeros(3)
+    zp = z.ctypes.data_as(ctypes.c_void_p)
+    assert lib.vsmpc_rollout_create(None, 4, zp, zp, 1, zp, 1, 0.1, ctypes.byref(r)) == -1
+    assert lib.vsmpc_rollout_reset(None, zp, zp) == -1
+    assert lib.vsmpc_rollout_run(None, 1, None, None) == -1
+    assert lib.vsmpc_rollout_get_state(None, zp) == -1 and lib.vsmpc_rollout_get_records(None, zp) == -1
+    lib.vsmpc_rollout_destroy(None)                                                    # must be a no-op
 
 
 def test_missing_library_fails_loudly(pkg, monkeypatch):
