@@ -1248,7 +1248,9 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
                 double mu = 0.0;
                 const int ka = __popcll(Amask);
-                if (ka <= SMALL_SOLVE_MAX) {
+                if (ka == 0) {
+                    // every bound was released again: v = v_u, no multipliers
+                } else if (ka <= SMALL_SOLVE_MAX) {
                     // few active bounds: solved redundantly in every lane on wave-uniform values
                     mu = small_spd_solve_n<D::NV + 1>(ka, sP, Amask, bb, lane, bad);
                 } else {
