@@ -10,12 +10,14 @@
 //                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
-//   P3 cholesky    right-looking LL^T on 16x16 LDS tiles: one wavefront factors a whole panel (diagonal tile
-//                  and the rows below it, lane = row, pivots broadcast with v_readlane), trailing updates on MFMA
-//   P4 box QP      free back-substitution first; only if a throttle bound is violated: Schur complement
-//                  on the warped throttles + block principal pivoting in one wavefront
-//                                                            (constraintsVSMPC.cpp:338-365)
-//   P5 back-subst  joints from the factor
+//   P3 cholesky    right-looking LL^T on 16x16 tiles, trailing matrix in registers, trailing updates on MFMA; a panel
+//                  is factored lane = row (pivots broadcast with v_readlane) by up to three wavefronts that each repeat
+//                  the diagonal tile and take 48 of the rows below; wavefronts without panel rows invert finished
+//                  diagonal tiles (X_p) and scale the tiles left of them (G_pq = X_p L_pq)
+//   P4 box QP      backward pass over the throttle tiles with only the hold pin; only if a bound is violated: block
+//                  principal pivoting in one wavefront, dual form on P = X^T X for few violated bounds, primal form
+//                  on the Schur complement otherwise, small systems in registers   (constraintsVSMPC.cpp:338-365)
+//   P5 back-subst  joints from the factor without a chain: w_q -= G_pq^T w_p, then z_p = X_p^T w_p
 //   P6 simulate    state trajectory, primal in the reference variable order, first-move block
 //                                                            (variableSamplingMPC.cpp:93-108,138-151)
 //
