@@ -1047,18 +1047,25 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         constexpr int PL = D::NT - 1, KL = D::NZ - 16 * PL;
         static_assert(KL == D::NV - 16 && KL >= 4, "pins live in the last tile row");
         const double* X6 = sXinv + PV * D::TS;
+        const double* L76 = Lb + tile_off<D>(PL, PV);
         const double* L77 = Lb + tile_off<D>(PL, PL);
         if (wave == 0) {
+            // wavefront 0 runs both throttle tile rows back to back in registers (cross-lane traffic through
+            // v_readlane only): one workgroup barrier instead of three before the joints' right-hand side is updated
             const int j = lane & 15;
             const int gj = 16 * PL + j;
             const double* Tpp = L77 + j;
-            double colv[KL];
+            double colv[KL], l76[KL], x6[16];
 #pragma unroll
             for (int k = 0; k < KL; ++k) {  // column j of L_pp; above the diagonal the tile holds leftovers
                 const double t = Tpp[k * 17];
                 colv[k] = k >= j ? t : 0.0;
+                l76[k] = L76[k * 17 + j];   // L[16 PL + k][16 PV + j]
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x6[i] = X6[i * 17 + j];
             double w = sW[gj];
+            double w6 = sW[16 * PV + j];
             const bool fix = (j >= KL) || (hold && j >= KL - 4);
             const double inv_eff = fix ? 0.0 : sInvD[gj];
             const double zadd = (fix && j < KL) ? sZ[gj] : 0.0;
@@ -1068,43 +1075,29 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 const double zk = readlane_f64(fma(w, inv_eff, zadd), k);
                 z = (j == k) ? zk : z;
                 w = fma(-colv[k], zk, w);
+                w6 = fma(-l76[k], zk, w6);  // right-hand side of the first throttle tile row, lane = row
             }
-            if (lane < 16) sZ[gj] = z;
-        }
-        __syncthreads();
-        if (tid < 16 * PL) {
-            const double* T = Lb + tile_off<D>(PL, tid >> 4) + (tid & 15);
-            const double* zp = sZ + 16 * PL;
-            double a0 = 0.0, a1 = 0.0;
+            double z6 = 0.0;                // z = X66^T w6: lane j sums X66[i][j] w6[i]
 #pragma unroll
-            for (int k = 0; k < KL; k += 2) {
-                a0 = fma(T[k * 17], zp[k], a0);
-                a1 = fma(T[(k + 1) * 17], zp[k + 1], a1);
-            }
-            sW[tid] -= a0 + a1;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            if (lane < 16) {
-                const double* wp = sW + 16 * PV;
-                double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    z0 = fma(X6[i * 17 + lane], wp[i], z0);
-                    z1 = fma(X6[(i + 1) * 17 + lane], wp[i + 1], z1);
-                }
-                sZ[16 * PV + lane] = z0 + z1;
-            }
+            for (int i = 0; i < 16; ++i) z6 = fma(x6[i], readlane_f64(w6, i), z6);
+            if (lane < 16) { sZ[gj] = z; sZ[16 * PV + j] = z6; }
         }
         __syncthreads();
         if (tid < 16 * PV) {
-            const double* T = Lb + tile_off<D>(PV, tid >> 4) + (tid & 15);
-            const double* zp = sZ + 16 * PV;
+            const double* T7 = Lb + tile_off<D>(PL, tid >> 4) + (tid & 15);
+            const double* T6 = Lb + tile_off<D>(PV, tid >> 4) + (tid & 15);
+            const double* z7 = sZ + 16 * PL;
+            const double* z6 = sZ + 16 * PV;
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
+            for (int k = 0; k < KL; k += 2) {
+                a0 = fma(T7[k * 17], z7[k], a0);
+                a1 = fma(T7[(k + 1) * 17], z7[k + 1], a1);
+            }
+#pragma unroll
             for (int k = 0; k < 16; k += 2) {
-                a0 = fma(T[k * 17], zp[k], a0);
-                a1 = fma(T[(k + 1) * 17], zp[k + 1], a1);
+                a0 = fma(T6[k * 17], z6[k], a0);
+                a1 = fma(T6[(k + 1) * 17], z6[k + 1], a1);
             }
             sW[tid] -= a0 + a1;
         }
