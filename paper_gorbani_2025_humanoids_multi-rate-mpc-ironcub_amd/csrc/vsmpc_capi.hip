@@ -2,6 +2,7 @@
 // No compute fallback lives here: every numeric result comes from the HIP kernels.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -28,7 +29,13 @@ struct vsmpc_handle {
     double* d_dbg;  // M | L for one instance
     double* d_ws;   // factor workspace for horizons whose factor does not fit LDS (max_batch instances)
     hipEvent_t ev0, ev1;
+    // small batches through the host-pointer entry (the reference's own use: one instance per tick): pinned,
+    // device-mapped staging that the kernel reads and writes directly, instead of five small copies
+    double* h_stage;      // host view:  in[ZC_MAX][n_in] | x[ZC_MAX][n_var] | fm[ZC_MAX][24] | status[ZC_MAX] | iters[ZC_MAX]
+    double* d_stage;      // device view of the same allocation
 };
+
+constexpr int ZC_MAX = 8;  // largest batch served through the mapped staging buffer
 
 // resident closed-loop state of a batch (uses the handle's record / first-move / status buffers as its per-tick scratch)
 struct vsmpc_rollout {
@@ -155,6 +162,11 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     if (e == hipSuccess) e = hipMalloc(&h->d_dbg, size_t(2) * h->n_p * h->n_p * sizeof(double));
     if (e == hipSuccess && variant_workspace_doubles(variant) > 0)
         e = hipMalloc(&h->d_ws, B * variant_workspace_doubles(variant) * sizeof(double));
+    if (e == hipSuccess) {
+        const size_t zc = size_t(ZC_MAX) * (h->n_in + h->n_var + VSMPC_FM_SIZE + 1) * sizeof(double);  // ints share one double
+        e = hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), zc, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_stage), h->h_stage, 0);
+    }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -176,6 +188,7 @@ void vsmpc_destroy(vsmpc_handle* h) {
     if (h->d_lin) (void)hipFree(h->d_lin);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -205,6 +218,26 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(h->device));
     const size_t B = size_t(batch);
+    if (batch <= ZC_MAX) {
+        // zero-copy path: the kernel reads the records from and writes the results to pinned host memory
+        double* hin = h->h_stage;
+        double* hx = hin + size_t(ZC_MAX) * h->n_in;
+        double* hfm = hx + size_t(ZC_MAX) * h->n_var;
+        int* hst = reinterpret_cast<int*>(hfm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
+        int* hit = hst + ZC_MAX;
+        const ptrdiff_t off = h->d_stage - h->h_stage;   // device view = host view + off (same allocation)
+        memcpy(hin, in, B * h->n_in * sizeof(double));
+        HIP_TRY(launch_solve(h->variant, h->dev, hin + off, batch, hx + off, hfm + off,
+                             reinterpret_cast<int*>(reinterpret_cast<double*>(hst) + off),
+                             reinterpret_cast<int*>(reinterpret_cast<double*>(hst) + off) + ZC_MAX, nullptr, nullptr,
+                             nullptr, h->d_ws, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (x) memcpy(x, hx, B * h->n_var * sizeof(double));
+        if (first_move) memcpy(first_move, hfm, B * VSMPC_FM_SIZE * sizeof(double));
+        memcpy(status, hst, B * sizeof(int));
+        if (iters) memcpy(iters, hit, B * sizeof(int));
+        return VSMPC_OK;
+    }
     HIP_TRY(hipMemcpyAsync(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
                          nullptr, nullptr, h->d_ws, s));
