@@ -1167,6 +1167,12 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 schur_rhs<D>(Lb, sSvec, lane);
             }
             __syncthreads();
+            if (wave == 3) {  // max |s| while wavefronts 0..1 finish X (keeps it off wavefront 0's path)
+                double gm = 0.0;
+#pragma unroll
+                for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
+                if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
+            }
             if (tid < 16 * NR2) {
                 const int a2 = tid >> 4, j = tid & 15;
                 double t = 0.0;
@@ -1192,10 +1198,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
             const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
             const double* X6 = sXinv + PV * D::TS;  // X[i][j], i, j < 16, at i*17 + j; rows 16.. are in sXr (sweep_tile)
-            double gmax = 0.0;
-#pragma unroll
-            for (int c = 0; c < D::NV; ++c) gmax = fmax(gmax, fabs(sSvec[c]));  // uniform addresses, in-order LDS
-            const double gtol = 1e-10 * (1.0 + gmax);
+            const double gtol = 1e-10 * (1.0 + sSvec[0]);   // sSvec[0] = max |s| (see above)
             const double vu = sZ[D::NU + r];
             // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
             // backward sweep that just ran.  Apply its flips here; nothing is at a bound yet, so only primal
