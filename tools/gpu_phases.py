@@ -7,8 +7,8 @@ PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
 import __graft_entry__ as ge
 ge.build()
 pkg = importlib.import_module(PKG); synth = importlib.import_module(PKG + ".synth"); solver = importlib.import_module(PKG + ".solver")
-names = ["P0 load+linearise", "P1 condense (propagate + MFMA SYRK)", "P2 augment", "P3 cholesky", "P4a schur build",
-         "P4b box-QP (BPP)", "P5 back-subst", "P6 simulate", "output"]
+names = ["P0 load+linearise", "P1 condense (propagate + MFMA SYRK)", "P2 augment", "P3 cholesky", "P4a throttle pass",
+         "P4b box QP", "P5 back-subst", "P6 simulate", "output"]
 import sys as _s
 cfg = pkg.horizon2x_config() if (len(_s.argv) > 1 and _s.argv[1] == "h2x") else pkg.paper_config()
 for wl, B in ((("hover", 256), ("takeoff", 256)) if len(_s.argv) > 1 else (("hover", 256), ("takeoff", 256), ("hover", 4096))):
