@@ -64,6 +64,74 @@ def parity_sample(cfg_name: str, inputs: np.ndarray, x: np.ndarray, k: int = 8) 
     return worst
 
 
+# BASELINE.json configs[2], [3] (the per-GPU slice of the 32768-instance Monte-Carlo batch: 4096 per GPU, seeds as
+# sharding.rank_inputs builds them for an 8-GPU node) and [4], at full size
+EXTRA_CONFIGS = (
+    {"name": "configs[2] batch=4096 take-off + disturbance seeds", "config": "paper", "workload": "takeoff",
+     "batch": 4096, "steps": 40, "warmup": 4},
+    {"name": "configs[3] Monte-Carlo (4 sigma), 4096 per GPU (rank slice of 32768 over 8 GPUs)", "config": "paper",
+     "workload": "montecarlo", "batch": 4096, "steps": 40, "warmup": 4, "global_total": 32768},
+    {"name": "configs[4] 2x horizon, batch=4096", "config": "horizon2x", "workload": "hover", "batch": 4096,
+     "steps": 12, "warmup": 2},
+)
+
+
+def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, world, distributed):
+    """One extra configuration: every rank solves its own `batch`-instance slice; max-over-ranks timing."""
+    import torch
+    import torch.distributed as dist
+    cfg = pkg.paper_config() if spec["config"] == "paper" else pkg.horizon2x_config()
+    B = spec["batch"]
+    if "global_total" in spec:       # configs[3]: rank r of an 8-GPU node owns instances [r*4096, (r+1)*4096)
+        slots = spec["global_total"] // B
+        inputs = sharding.rank_inputs(cfg, synth, spec["global_total"], rank % slots, slots, workload=spec["workload"])
+    else:
+        first, count = sharding.shard_range(B * world, rank, world)
+        inputs = synth.make_batch(cfg, count, workload=spec["workload"], first_index=first)
+    mpc = solver.BatchedVSMPC(cfg, device=local_rank, max_batch=B)
+    d_in = torch.from_numpy(inputs).to(dev)
+    d_x = torch.empty((B, cfg.n_var), dtype=torch.float64, device=dev)
+    d_fm = torch.empty((B, 24), dtype=torch.float64, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    d_it = torch.empty(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(1 + spec["warmup"]):
+        mpc.solve_device(d_in, d_x, d_fm, d_st, d_it, stream)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    mpc.timing_begin(stream)
+    for _ in range(spec["steps"]):
+        mpc.solve_device(d_in, d_x, d_fm, d_st, d_it, stream)
+    kernel_ms = mpc.timing_end(stream, spec["steps"])
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([int((d_st == 1).sum().item()), int(d_it.sum().item())], dtype=torch.int64, device=dev)
+    if distributed:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    rec = None
+    if rank == 0:
+        elapsed, kernel_ms = float(red[0].item()), float(red[1].item())
+        tf = F_ALG[spec["config"]] * B / (kernel_ms * 1e-3) / 1e12
+        x_host = d_x.cpu().numpy()
+        rec = {"name": spec["name"], "config": spec["config"], "workload": spec["workload"], "batch_per_gpu": B,
+               "n_gpus": world, "steps": spec["steps"], "value": B * world * spec["steps"] / elapsed, "unit": "solves/s",
+               "ms_per_step": 1e3 * elapsed / spec["steps"], "kernel": mpc.kernel_name,
+               "kernel_us_per_launch": kernel_ms * 1e3, "kernel_us_per_256": kernel_ms * 1e3 * 256 / B,
+               "roofline_frac": tf / FP64_PEAK_TFLOPS, "achieved_tflops": tf,
+               "solved": int(cnt[0].item()), "instances_per_step": B * world,
+               "mean_active_set_iterations": float(cnt[1].item()) / (B * world),
+               "parity_max_rel_err_vs_oracle": parity_sample(spec["config"], inputs, x_host, k=6)}
+    mpc.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +142,7 @@ def main():
     ap.add_argument("--config", default="paper", choices=["paper", "horizon2x"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs array (BASELINE configs[2..4])")
     args = ap.parse_args()
 
     import torch
@@ -196,10 +265,23 @@ def main():
             one.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, inputs)
+
+    # BASELINE.json configs[2..4] at full size, appended to the same line (every rank runs its own slice; `value` stays
+    # on configs[1]).  Skipped when the caller picked a non-default workload itself.
+    mpc.close()
+    default_line = args.config == "paper" and args.workload == "hover" and B == 256
+    if default_line and not args.no_extra:
+        extra = []
+        for spec in EXTRA_CONFIGS:
+            rec = measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, world, distributed)
+            if rank == 0:
+                extra.append(rec)
+        if rank == 0:
+            out["extra_configs"] = extra
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     barrier()
-    mpc.close()
     if distributed:
         dist.destroy_process_group()
 
