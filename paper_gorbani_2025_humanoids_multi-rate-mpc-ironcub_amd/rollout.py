@@ -124,6 +124,18 @@ def make_trajectory(cfg: L.MPCConfig, workload: str = "hover", horizon_s: float 
     return pos, vel, alpha, alpha_dt
 
 
+def load_reference_trajectories(npz_path: str):
+    """(pos[n,3], vel[n,3], alpha[m], alpha_dt) from an npz holding the reference's own trajectory arrays
+    (`positionCoM`, `velocityCoM` [n,3], `alphaGravity` [m], `trajectory_fps`, `alphaGravity_fps`): the content of
+    src/trajectories/{minimumJerkTrajectory,alphaGravity}.mat as plain arrays (tools/gen_reference_constants.py writes
+    tests/golden/reference_trajectories.npz; MAT-7.3 reading itself stays outside the path)."""
+    d = np.load(npz_path)
+    pos = np.ascontiguousarray(d["positionCoM"], dtype=np.float64)
+    vel = np.ascontiguousarray(d["velocityCoM"], dtype=np.float64)
+    alpha = np.ascontiguousarray(d["alphaGravity"], dtype=np.float64).reshape(-1)
+    return pos, vel, alpha, 1.0 / float(d["alphaGravity_fps"].reshape(-1)[0])
+
+
 class ClosedLoopRollout:
     """`batch` closed loops resident on one GPU.  reset() uploads plant states, run(ticks) advances them."""
 
