@@ -229,6 +229,11 @@ def main():
         if os.path.exists(tpath):
             rec = json.load(open(tpath)).get(f"{args.config}:{args.workload}:{B}")
             traffic = rec["bytes_per_launch"] if rec else None
+        mfma_busy = None
+        mpath = os.path.join(ROOT, "profiles", "mfma_counters.json")
+        if os.path.exists(mpath):   # SQ_VALU_MFMA_BUSY_CYCLES share, separate rocprofv3 --pmc pass (tools/prof_mfma.sh)
+            rec = json.load(open(mpath)).get(f"{args.config}:{args.workload}:{B}")
+            mfma_busy = rec["mfma_busy_frac"] if rec else None
         out = {
             # BASELINE.json's metric; `value` is the solves/s part, the p50 latency part is `latency_single_solve_us`
             "metric": "MPC solves/sec (whole node) + p50 single-solve latency, iRonCub paper horizon"
@@ -241,7 +246,7 @@ def main():
                        "instances_total": total, "qp": f"{cfg.n_var} vars / {cfg.n_con} rows",
                        "parallelism": f"batch split over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,
                          "kernel": mpc.kernel_name, "kernel_us_per_launch": kernel_ms * 1e3,
                          "alg_flops_per_solve": F_ALG[args.config], "alg_bytes_per_solve": BYTES_ALG[args.config],
                          "hbm_frac_informational": BYTES_ALG[args.config] * count / (kernel_ms * 1e-3) / 8.0e12},
