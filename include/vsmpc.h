@@ -20,6 +20,8 @@
 #ifndef VSMPC_H
 #define VSMPC_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -110,8 +112,12 @@ typedef struct vsmpc_handle vsmpc_handle;
 
 /* Replaces IMPCProblem::configure (IMPCProblem.cpp:3-148) + VariableSamplingMPC::setCostAndConstraints
  * (variableSamplingMPC.cpp:7-86): validates the configuration, selects the kernel instantiation and
- * allocates device buffers for `max_batch` instances on HIP device `device`.  No allocation happens
- * in any later call. */
+ * allocates every device and staging buffer for `max_batch` instances on HIP device `device` (solve, linearise,
+ * kinematics, diagnostics).  No allocation happens in any later call on the handle; a rollout object allocates at its
+ * own create and grows its log buffer only when a longer logged run is requested.
+ * Horizons: any (nIter, nIterSmall, controlHorizon) listed in csrc/vsmpc_horizons.def has a kernel instantiation
+ * (the kernels are straight-line code generated per horizon); others return VSMPC_ERR_UNSUPPORTED_CONFIG -- add the
+ * horizon to VSMPC_HORIZONS and rebuild. */
 int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handle** out);
 void vsmpc_destroy(vsmpc_handle* h);
 
@@ -130,7 +136,7 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
                       int* status, int* iters, void* stream);
 
 /* Same, all pointers are DEVICE pointers and the call only enqueues work on `stream` (no copies,
- * no synchronisation): the form a resident batch driver uses. */
+ * no synchronisation): the form a resident batch driver uses.  batch <= vsmpc_max_batch(h). */
 int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, double* d_x,
                              double* d_first_move, int* d_status, int* d_iters, void* stream);
 
@@ -243,6 +249,12 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream);
  * hook: after reset the records of tick 0, after run(k) those of tick k). */
 int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state);
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
+
+/* Pinned host memory for the caller's in/x/first_move/status buffers (thin wrappers of hipHostMalloc / hipHostFree,
+ * so that a C caller need not link the HIP runtime): with pinned buffers vsmpc_solve_batch overlaps upload, solve and
+ * download chunk by chunk.  Returns NULL on failure. */
+void* vsmpc_alloc_host(size_t bytes);
+void vsmpc_free_host(void* p);
 
 const char* vsmpc_strerror(int code);
 const char* vsmpc_kernel_name(const vsmpc_handle* h);

@@ -17,7 +17,7 @@ EXPORTS = (
     "vsmpc_assemble_dense", "vsmpc_condensed_dim", "vsmpc_debug_condensed", "vsmpc_timing_begin",
     "vsmpc_timing_end", "vsmpc_strerror", "vsmpc_kernel_name", "vsmpc_debug_phase_cycles", "vsmpc_kinematics_batch",
     "vsmpc_rollout_create", "vsmpc_rollout_destroy", "vsmpc_rollout_reset", "vsmpc_rollout_run",
-    "vsmpc_rollout_get_state", "vsmpc_rollout_get_records",
+    "vsmpc_rollout_get_state", "vsmpc_rollout_get_records", "vsmpc_alloc_host", "vsmpc_free_host",
 )
 
 _lib = None
@@ -79,6 +79,10 @@ def load():
     lib.vsmpc_rollout_get_state.restype = c_int
     lib.vsmpc_rollout_get_records.argtypes = [vp, dp]
     lib.vsmpc_rollout_get_records.restype = c_int
+    lib.vsmpc_alloc_host.argtypes = [ctypes.c_size_t]
+    lib.vsmpc_alloc_host.restype = vp
+    lib.vsmpc_free_host.argtypes = [vp]
+    lib.vsmpc_free_host.restype = None
     lib.vsmpc_strerror.argtypes = [c_int]
     lib.vsmpc_strerror.restype = ctypes.c_char_p
     lib.vsmpc_kernel_name.argtypes = [vp]

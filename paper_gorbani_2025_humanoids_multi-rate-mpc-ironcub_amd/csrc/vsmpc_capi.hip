@@ -27,15 +27,23 @@ struct vsmpc_handle {
     int* d_iters;
     double* d_lin;  // A | Bj | Bt | c for max_batch instances
     double* d_dbg;  // M | L for one instance
-    double* d_ws;   // factor workspace for horizons whose factor does not fit LDS (max_batch instances)
+    double* d_kin;  // vsmpc_kinematics_batch: records in, terms out (max_batch instances)
+    double* d_kout;
+    unsigned long long* d_stamps;  // vsmpc_debug_phase_cycles (max_batch x 16)
     hipEvent_t ev0, ev1;
+    // host-pointer entry for larger batches: chunks alternate between two streams so that the upload of one chunk, the
+    // solve of the previous one and the download of the one before overlap (full overlap needs pinned caller buffers)
+    hipStream_t pipe[2];
+    hipEvent_t pipe_done[2];
+    hipEvent_t pipe_start;
     // small batches through the host-pointer entry (the reference's own use: one instance per tick): pinned,
     // device-mapped staging that the kernel reads and writes directly, instead of five small copies
     double* h_stage;      // host view:  in[ZC_MAX][n_in] | x[ZC_MAX][n_var] | fm[ZC_MAX][24] | status[ZC_MAX] | iters[ZC_MAX]
-    double* d_stage;      // device view of the same allocation
+    double* d_stage;      // device view of the same allocation (its own base pointer: the two views are unrelated addresses)
 };
 
 constexpr int ZC_MAX = 8;  // largest batch served through the mapped staging buffer
+constexpr int PIPE_CHUNK = 1024;  // instances per chunk of the pipelined host-pointer entry
 
 // resident closed-loop state of a batch (uses the handle's record / first-move / status buffers as its per-tick scratch)
 struct vsmpc_rollout {
@@ -160,8 +168,14 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     if (e == hipSuccess) e = hipMalloc(&h->d_iters, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&h->d_lin, B * (NX * NX + NX * NJ + NX * NTH + NX) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->d_dbg, size_t(2) * h->n_p * h->n_p * sizeof(double));
-    if (e == hipSuccess && variant_workspace_doubles(variant) > 0)
-        e = hipMalloc(&h->d_ws, B * variant_workspace_doubles(variant) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_kin, B * VSMPC_KIN_SIZE * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_kout, B * VSMPC_KIN_OUT * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&h->d_stamps, B * 16 * sizeof(unsigned long long));
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pipe_done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pipe_start, hipEventDisableTiming);
     if (e == hipSuccess) {
         const size_t zc = size_t(ZC_MAX) * (h->n_in + h->n_var + VSMPC_FM_SIZE + 1) * sizeof(double);  // ints share one double
         e = hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), zc, hipHostMallocMapped);
@@ -187,7 +201,14 @@ void vsmpc_destroy(vsmpc_handle* h) {
     if (h->d_iters) (void)hipFree(h->d_iters);
     if (h->d_lin) (void)hipFree(h->d_lin);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
-    if (h->d_ws) (void)hipFree(h->d_ws);
+    if (h->d_kin) (void)hipFree(h->d_kin);
+    if (h->d_kout) (void)hipFree(h->d_kout);
+    if (h->d_stamps) (void)hipFree(h->d_stamps);
+    for (int i = 0; i < 2; ++i) {
+        if (h->pipe[i]) (void)hipStreamDestroy(h->pipe[i]);
+        if (h->pipe_done[i]) (void)hipEventDestroy(h->pipe_done[i]);
+    }
+    if (h->pipe_start) (void)hipEventDestroy(h->pipe_start);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -204,9 +225,11 @@ const char* vsmpc_kernel_name(const vsmpc_handle* h) { return h ? variant_kernel
 int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, double* d_x, double* d_first_move,
                              int* d_status, int* d_iters, void* stream) {
     if (h == nullptr || d_in == nullptr || d_status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(launch_solve(h->variant, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
-                         nullptr, h->d_ws, static_cast<hipStream_t>(stream)));
+                         nullptr, static_cast<hipStream_t>(stream)));
     return VSMPC_OK;
 }
 
@@ -225,12 +248,13 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         double* hfm = hx + size_t(ZC_MAX) * h->n_var;
         int* hst = reinterpret_cast<int*>(hfm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
         int* hit = hst + ZC_MAX;
-        const ptrdiff_t off = h->d_stage - h->h_stage;   // device view = host view + off (same allocation)
+        double* din = h->d_stage;                              // the same carve-up on the device view
+        double* dx = din + size_t(ZC_MAX) * h->n_in;
+        double* dfm = dx + size_t(ZC_MAX) * h->n_var;
+        int* dst = reinterpret_cast<int*>(dfm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
+        int* dit = dst + ZC_MAX;
         memcpy(hin, in, B * h->n_in * sizeof(double));
-        HIP_TRY(launch_solve(h->variant, h->dev, hin + off, batch, hx + off, hfm + off,
-                             reinterpret_cast<int*>(reinterpret_cast<double*>(hst) + off),
-                             reinterpret_cast<int*>(reinterpret_cast<double*>(hst) + off) + ZC_MAX, nullptr, nullptr,
-                             nullptr, h->d_ws, s));
+        HIP_TRY(launch_solve(h->variant, h->dev, din, batch, dx, dfm, dst, dit, nullptr, nullptr, nullptr, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (x) memcpy(x, hx, B * h->n_var * sizeof(double));
         if (first_move) memcpy(first_move, hfm, B * VSMPC_FM_SIZE * sizeof(double));
@@ -238,15 +262,32 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         if (iters) memcpy(iters, hit, B * sizeof(int));
         return VSMPC_OK;
     }
-    HIP_TRY(hipMemcpyAsync(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                         nullptr, nullptr, h->d_ws, s));
-    if (x) HIP_TRY(hipMemcpyAsync(x, h->d_x, B * h->n_var * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (first_move)
-        HIP_TRY(hipMemcpyAsync(first_move, h->d_fm, B * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(status, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters, B * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // chunks of PIPE_CHUNK instances alternate between the handle's two streams: upload(k+1) | solve(k) | download(k-1)
+    // overlap when the caller's buffers are pinned (hipHostMalloc / vsmpc_alloc_host); with pageable buffers the
+    // runtime stages the copies itself and the chunks still overlap with the kernels
+    HIP_TRY(hipEventRecord(h->pipe_start, s));                 // work queued on the caller's stream comes first
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(h->pipe[i], h->pipe_start, 0));
+    int k = 0;
+    for (int first = 0; first < batch; first += PIPE_CHUNK, ++k) {
+        const int n = std::min(PIPE_CHUNK, batch - first);
+        const size_t o = size_t(first), N = size_t(n);
+        hipStream_t ps = h->pipe[k & 1];
+        HIP_TRY(hipMemcpyAsync(h->d_in + o * h->n_in, in + o * h->n_in, N * h->n_in * sizeof(double), hipMemcpyHostToDevice, ps));
+        HIP_TRY(launch_solve(h->variant, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
+                             h->d_fm + o * VSMPC_FM_SIZE, h->d_status + o, h->d_iters + o, nullptr, nullptr, nullptr, ps));
+        if (x) HIP_TRY(hipMemcpyAsync(x + o * h->n_var, h->d_x + o * h->n_var, N * h->n_var * sizeof(double), hipMemcpyDeviceToHost, ps));
+        if (first_move)
+            HIP_TRY(hipMemcpyAsync(first_move + o * VSMPC_FM_SIZE, h->d_fm + o * VSMPC_FM_SIZE,
+                                   N * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, ps));
+        HIP_TRY(hipMemcpyAsync(status + o, h->d_status + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
+        if (iters) HIP_TRY(hipMemcpyAsync(iters + o, h->d_iters + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
+    }
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventRecord(h->pipe_done[i], h->pipe[i]));
+        HIP_TRY(hipStreamWaitEvent(s, h->pipe_done[i], 0));   // the caller's stream continues after both
+    }
+    HIP_TRY(hipStreamSynchronize(h->pipe[0]));
+    HIP_TRY(hipStreamSynchronize(h->pipe[1]));
     return VSMPC_OK;
 }
 
@@ -369,8 +410,9 @@ int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, doub
     HIP_TRY(hipSetDevice(h->device));
     const size_t np2 = size_t(h->n_p) * h->n_p;
     HIP_TRY(hipMemcpy(h->d_in, in_one, h->n_in * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->d_dbg, 0, 2 * np2 * sizeof(double)));   // the kernel writes the lower triangles only
     HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, 1, h->d_x, h->d_fm, h->d_status, h->d_iters, h->d_dbg,
-                         h->d_dbg + np2, nullptr, h->d_ws, nullptr));
+                         h->d_dbg + np2, nullptr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     if (M) HIP_TRY(hipMemcpy(M, h->d_dbg, np2 * sizeof(double), hipMemcpyDeviceToHost));
     if (Lfac) HIP_TRY(hipMemcpy(Lfac, h->d_dbg + np2, np2 * sizeof(double), hipMemcpyDeviceToHost));
@@ -379,19 +421,13 @@ int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, doub
 
 int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double* out, double* records) {
     if (h == nullptr || kin == nullptr || out == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
     HIP_TRY(hipSetDevice(h->device));
-    double* d_kin = nullptr;
-    double* d_out = nullptr;
-    hipError_t e = hipMalloc(&d_kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&d_out, size_t(batch) * VSMPC_KIN_OUT * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpy(d_kin, kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_kinematics(d_kin, batch, d_out, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(out, d_out, size_t(batch) * VSMPC_KIN_OUT * sizeof(double), hipMemcpyDeviceToHost);
-    if (d_kin) (void)hipFree(d_kin);
-    if (d_out) (void)hipFree(d_out);
-    if (e != hipSuccess) return hip_fail(e, "vsmpc_kinematics_batch");
+    HIP_TRY(hipMemcpy(h->d_kin, kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(launch_kinematics(h->d_kin, batch, h->d_kout, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_kout, size_t(batch) * VSMPC_KIN_OUT * sizeof(double), hipMemcpyDeviceToHost));
     if (records != nullptr) {  // patch the three fields of the input records (host side, layout bookkeeping only)
         for (int b = 0; b < batch; ++b) {
             double* rec = records + size_t(b) * h->n_in;
@@ -408,18 +444,14 @@ int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsig
     if (h == nullptr || in == nullptr || stamps16 == nullptr || batch <= 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     HIP_TRY(hipSetDevice(h->device));
-    unsigned long long* d_st = nullptr;
-    HIP_TRY(hipMalloc(&d_st, size_t(batch) * 16 * sizeof(unsigned long long)));
-    hipError_t e = hipMemset(d_st, 0, size_t(batch) * 16 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemcpy(h->d_in, in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 3 && e == hipSuccess; ++rep)  // warm instruction caches, keep the last run
-        e = launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                         nullptr, d_st, h->d_ws, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess)
-        e = hipMemcpy(stamps16, d_st, size_t(batch) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    (void)hipFree(d_st);
-    if (e != hipSuccess) return hip_fail(e, "vsmpc_debug_phase_cycles");
+    unsigned long long* d_st = h->d_stamps;
+    HIP_TRY(hipMemset(d_st, 0, size_t(batch) * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpy(h->d_in, in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 3; ++rep)  // warm instruction caches, keep the last run
+        HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+                             nullptr, d_st, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(stamps16, d_st, size_t(batch) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return VSMPC_OK;
 }
 
@@ -528,7 +560,7 @@ constexpr int GRAPH_TICKS = 25;  // ticks per captured graph (50 kernel nodes)
 hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
     vsmpc_handle* h = r->h;
     hipError_t e = launch_solve(h->variant, h->dev, r->d_rec, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
-                                nullptr, nullptr, h->d_ws, s);
+                                nullptr, nullptr, s);
     if (e == hipSuccess)
         e = launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
                            r->d_talpha, r->d_ctl, r->substeps, r->d_tpos, r->d_tvel, r->d_rec, s);
@@ -597,6 +629,16 @@ int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records) {
     HIP_TRY(hipSetDevice(r->h->device));
     HIP_TRY(hipMemcpy(records, r->d_rec, size_t(r->batch) * r->h->n_in * sizeof(double), hipMemcpyDeviceToHost));
     return VSMPC_OK;
+}
+
+void* vsmpc_alloc_host(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void vsmpc_free_host(void* p) {
+    if (p != nullptr) (void)hipHostFree(p);
 }
 
 const char* vsmpc_strerror(int code) {

@@ -42,16 +42,32 @@ struct Dims {
     // Y row stride (doubles), congruent 16 mod 32: the four row groups of a b64 operand read hit distinct banks
     static constexpr int YS = ((NP + 16) % 32 == 16) ? NP + 16 : NP + 32;
     static constexpr int TS = 16 * 17;       // tile stride (16 rows, padded row stride 17)
-    // workgroup shape: the sensitivity recursion runs one condensed column per thread and per half (linear /
-    // angular), so the workgroup needs 2 * NP threads: 256 for the paper horizon, 512 for the 2x horizon
-    static constexpr int BLOCK = NP <= 128 ? 256 : 512;
+    // workgroup shape: four wavefronts (one per SIMD) for every horizon.  The sensitivity recursion runs one thread per
+    // (half, column) pair -- half = linear / angular part -- on 128 columns at a time: CPT columns per thread.
+    // Short horizons (NP <= 128) need <= 256 registers and <= 80 KB of LDS, so two workgroups share a CU; long horizons
+    // hold 30 accumulator tiles per wavefront in the 512-register budget of one wavefront per SIMD.
+    static constexpr int BLOCK = 256;
     static constexpr int NWAVES = BLOCK / 64;
     static constexpr int PCOLS = BLOCK / 2;
-    static_assert(NP <= PCOLS, "one condensed column per thread pair");
-    // The factor's tiles live in LDS (reusing the two Y buffers) when they fit; otherwise (2x horizon: 120 tiles =
-    // 261 KB) they live in a per-instance global workspace that stays L2/Infinity-Cache resident, and Y is single-buffered.
-    static constexpr bool L_IN_LDS = (NTRI * TS) <= (2 * 36 * YS);
-    static constexpr size_t L_WORKSPACE_DOUBLES = L_IN_LDS ? 0 : size_t(NTRI) * TS;
+    static constexpr int CPT = (NP + PCOLS - 1) / PCOLS;
+    static constexpr int WG_PER_CU = NP <= 128 ? 2 : 1;
+    // shared panels: a wavefront carries the diagonal tile in lanes 0..15 of its first row slot and PANEL_RPW rows below
+    // it in the remaining lanes of PANEL_SLOTS slots of 64 rows; at most NWAVES - 1 wavefronts share a panel
+    static constexpr int PANEL_SLOTS = (NP - 16 + 48 * (NWAVES - 1) - 1) / (48 * (NWAVES - 1)) <= 1 ? 1 : 2;
+    static_assert((NP - 16 + (64 * PANEL_SLOTS - 16) - 1) / (64 * PANEL_SLOTS - 16) <= NWAVES - 1, "panel 0 leaves one wavefront for the side work");
+    // Where the factor lives (v10).  The trailing matrix and, after its column has been the panel, every finished
+    // off-diagonal tile of L stay in the REGISTERS of the wavefront that owns the tile.  LDS only ever holds
+    //   * a ring of two panel columns (column p while it is factored / applied, column p+1 being handed over),
+    //   * the throttle corner (tile rows and columns >= PVT: the box QP works on it), and
+    //   * the inverses X_p of the joint diagonal tiles (back-substitution without a chain).
+    // That is 15 + 3 + 7 tiles at the paper horizon instead of the 36 + 8 + 15 of the LDS-resident factor, which is
+    // what lets two workgroups share one CU (<= 80 KB each).  Nothing lives in global memory for any horizon.
+    static constexpr int PVT = NU >> 4;                      // first tile row that contains a throttle row
+    static constexpr int RING_A = NT;                        // tiles of an even panel column (at most NT)
+    static constexpr int RING_TILES = 2 * NT - 1;            // + an odd one (at most NT - 1)
+    static constexpr int NCORNER = (NT - PVT) * (NT - PVT + 1) / 2;
+    static constexpr int L_TILES = RING_TILES + NCORNER;     // LDS tiles addressed through tile_off()
+    static_assert(PVT >= 1 && PVT < NT, "throttle corner");
     static_assert(N <= MAX_STAGES, "horizon too long");
     static_assert(NV <= 64, "throttle block must fit one wavefront");
 };

@@ -4,20 +4,23 @@
 // (IMPCProblem.cpp:150-298, variableSamplingMPC.cpp:88-112) with a structure-exploiting exact solve:
 //
 //   P0 linearise   A, Bj, Bt, c in LDS                       (systemDynamicsVSMPC.cpp:79-103,288-319,384-429)
-//   P1 condense    sensitivity recursion in registers: thread (half, col) carries the linear-momentum
-//                  half (p, h_lin, e_pos | T, Tdot) or the angular half (rpy, h_ang, e_rpy | T, Tdot) of
+//   P1 condense    jet thrust sensitivities first (one two-state recursion per throttle column, four for the affine
+//                  column), then the sensitivity recursion in registers: thread (half, col) carries the
+//                  linear-momentum half (p, h_lin, e_pos) or the angular half (rpy, h_ang, e_rpy) of
 //                  one condensed column; two nodes (36 weighted rows = 9 exact MFMA k-steps) per pass;
 //                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
-//   P3 cholesky    right-looking LL^T on 16x16 tiles, trailing matrix in registers, trailing updates on MFMA; a panel
-//                  is factored lane = row (pivots broadcast with v_readlane) by up to three wavefronts that each repeat
-//                  the diagonal tile and take 48 of the rows below; wavefronts without panel rows invert finished
-//                  diagonal tiles (X_p) and scale the tiles left of them (G_pq = X_p L_pq)
+//   P3 cholesky    right-looking LL^T on 16x16 tiles; the trailing matrix AND the finished factor stay in registers,
+//                  LDS holds a ring of two panel columns + the throttle corner; trailing updates on MFMA; a panel is
+//                  factored lane = row (pivots broadcast with v_readlane) by up to three wavefronts that each repeat
+//                  the diagonal tile and take 48 of the rows below; a wavefront without panel rows inverts the
+//                  finished diagonal tiles (X_p)
 //   P4 box QP      backward pass over the throttle tiles with only the hold pin; only if a bound is violated: block
 //                  principal pivoting in one wavefront, dual form on P = X^T X for few violated bounds, primal form
 //                  on the Schur complement otherwise, small systems in registers   (constraintsVSMPC.cpp:338-365)
-//   P5 back-subst  joints from the factor without a chain: w_q -= G_pq^T w_p, then z_p = X_p^T w_p
+//   P5 back-subst  joints from the register-resident factor, tile row by tile row: z_r = X_r^T (w_r - u_r), then every
+//                  wavefront adds L_rq^T z_r of the tiles it owns to its partial sums u_q
 //   P6 simulate    state trajectory, primal in the reference variable order, first-move block
 //                                                            (variableSamplingMPC.cpp:93-108,138-151)
 //
@@ -66,10 +69,17 @@ VS_DEV double fast_rcp(double d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS carve-up (doubles)
+// LDS carve-up (doubles).  One region R is reused phase by phase:
+//   P1      the Y buffer (two nodes x 18 weighted rows x YS)
+//   P3      the ring of two panel columns + the throttle corner (Dims::L_TILES tiles, see vsmpc_device.hpp)
+//   P4..P6  over the (by then dead) ring: box-QP work arrays, the per-wavefront partial sums of the register
+//           back-substitution, the state trajectory and the stage forcing terms; the corner stays where it is
+// Paper horizon: 71 KB in total, so two workgroups fit one CU.
 // ------------------------------------------------------------------------------------------------
 template <class D>
 struct Smem {
+    // the dual box QP and the chain-free first pass need the throttle block to span exactly two tile rows
+    static constexpr bool DUALQP = D::NT - 2 == D::PVT && D::NU % 16 == 0 && D::NV >= 20 && D::NV <= 32;
     static constexpr int oIn = 0;
     static constexpr int oA = oIn + ((D::NIN + 3) & ~3);
     static constexpr int oBj = oA + NX * NX;
@@ -79,41 +89,46 @@ struct Smem {
     static constexpr int oInvD = oVprev + 4;
     static constexpr int oW = oInvD + D::NP;
     static constexpr int oZ = oW + D::NP;
-    static constexpr int oSv = oZ + D::NP;
-    static constexpr int oSvec = oSv + D::NV * (D::NV + 1);
+    static constexpr int oSvec = oZ + D::NP;
     static constexpr int oV = oSvec + D::NV;
-    static constexpr int oX = oV + D::NV;
-    static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
-    static constexpr int oDt = oF + NX * D::N;       // per-stage dt (copied out of the kernel arguments once)
+    static constexpr int oDt = oV + D::NV;           // per-stage dt (copied out of the kernel arguments once)
     static constexpr int oFlags = oDt + MAX_STAGES;  // 4 doubles worth of int flags
-    static constexpr int oEllV = oFlags + 4;         // P6: sparse rows of A, 8 entries per state row
-    static constexpr int oEllC = oEllV + NX * 8;     // (ints, 8 per row -> NX*4 doubles)
-    static constexpr int oY = (oEllC + NX * 4 + 3) & ~3;
+    // X_p = L_pp^-1 of the joint diagonal tiles and of the first throttle tile, produced by wavefronts that idle
+    // during the panel factorisations of P3
+    static constexpr int NXT = D::PVT + 1;
+    static constexpr int oXinv = (oFlags + 4 + 3) & ~3;
+    static constexpr int oR = oXinv + NXT * D::TS;
     static constexpr int YROWS = 36;                 // two nodes x 18 weighted rows = 9 exact MFMA k-steps
-    static constexpr int NYBUF = D::L_IN_LDS ? 2 : 1; // double-buffered when the budget allows
-    static constexpr int sizeY = NYBUF * YROWS * D::YS;
-    static constexpr int oM = oY;                    // the factor's tiles reuse the Y buffers (dead after P1)
-    static constexpr int sizeM = D::L_IN_LDS ? D::NTRI * D::TS : 0;
-    // P5 without a serial chain (paper horizon, where LDS has the room): X_p = L_pp^-1 of the joint diagonal tiles and
-    // G_pq = X_p L_pq of the joint tiles below them, both produced by the wavefronts that idle during the panel
-    // factorisations of P3
-    static constexpr bool FASTSWEEP = D::L_IN_LDS;
-    static constexpr int NJT = D::NU >> 4;           // joint tile rows
-    static constexpr int oXinv = oY + (sizeY > sizeM ? sizeY : sizeM);
-    static constexpr int sizeXinv = FASTSWEEP ? (NJT + 1) * D::TS : 0;  // + the first throttle tile (box QP, dual form)
-    static constexpr int oG = oXinv + sizeXinv;
-    static constexpr int sizeG = FASTSWEEP ? (NJT * (NJT - 1) / 2) * D::TS : 0;
-    static constexpr int total = oG + sizeG;
+    static constexpr int oY = oR;
+    static constexpr int sizeY = YROWS * D::YS;
+    static constexpr int oM = oR;                    // ring + corner tiles (Y is dead after P1)
+    static constexpr int sizeM = D::L_TILES * D::TS;
+    static constexpr int NVS = D::NV + 1;            // row stride of the box-QP work arrays
+    static constexpr int oSv = oR;                   // Schur complement / columns of P
+    static constexpr int oQP = oSv + D::NV * NVS;    // dual form only: K | rows 16.. of X
+    static constexpr int sizeQP = DUALQP ? D::NV * NVS + (D::NV - 16) * NVS : 0;
+    static constexpr int oU = oQP + sizeQP;          // per-wavefront partial sums of L^T z, NP each
+    static constexpr int oZw = oU + D::NWAVES * D::NP;  // per-wavefront scratch: d (16) | z (16)
+    static constexpr int oX = oZw + D::NWAVES * 32;  // P6: state trajectory
+    static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
+    static constexpr int endScratch = oF + NX * D::N;
+    static_assert(endScratch <= oR + D::RING_TILES * D::TS, "P4..P6 scratch must not reach the corner tiles");
+    static constexpr int total = oR + (sizeY > sizeM ? sizeY : sizeM);
     static constexpr size_t bytes = size_t(total) * sizeof(double);
     static_assert(bytes <= 160 * 1024, "LDS budget of one CU");
 };
 
+// tile (i, j), j <= i, of the factor in LDS: panel columns left of the throttle corner live in a ring of two
+// (even columns at tile 0, odd ones at tile RING_A), the corner is dense behind the ring
 template <class D>
-VS_DEV int tile_off(int i, int j) { return (i * (i + 1) / 2 + j) * D::TS; }
+VS_HD constexpr int tile_off_c(int i, int j) {
+    return (j < D::PVT ? (j & 1) * D::RING_A + (i - j)
+                       : D::RING_TILES + (i - D::PVT) * (i - D::PVT + 1) / 2 + (j - D::PVT)) * D::TS;
+}
 template <class D>
-constexpr int tile_off_c(int i, int j) { return (i * (i + 1) / 2 + j) * D::TS; }
+VS_DEV int tile_off(int i, int j) { return tile_off_c<D>(i, j); }
 
-// element (gr, gc), gc <= gr, of the lower-triangular tile storage
+// element (gr, gc), gc <= gr, of a tile that is currently in LDS
 template <class D>
 VS_DEV int lower_at(int gr, int gc) {
     return tile_off<D>(gr >> 4, gc >> 4) + (gr & 15) * 17 + (gc & 15);
@@ -256,34 +271,26 @@ VS_DEV double input_cost_term(const DevCfg& cfg, const double* __restrict__ sIn,
 }
 
 // ------------------------------------------------------------------------------------------------
-// One SYRK pass of P1 for the first NACT slots of this wavefront, NKS k-steps of 4 rows: branch-free so
-// that the compiler can count outstanding LDS loads; operands of k-step ks+1 are requested before the
-// matrix-core chain of k-step ks is issued.
+// SYRK of P1, one accumulator tile (slot) at a time: NKS k-steps of 4 rows as ONE dependent chain on the tile's
+// accumulator (a dependent v_mfma_f64_16x16x4_f64 issues every 64 cycles, like independent ones), operands of the
+// whole chain requested up front.  The caller walks the active slots with one scalar branch per slot; inside a slot
+// the code is branch-free so that the compiler can count the outstanding LDS loads.  (Through v9 a pass was one
+// straight-line stream over all active slots, instantiated per slot count: 630 static matrix-core instructions whose
+// accumulator phis cost a second set of accumulator registers -- unaffordable at two workgroups per CU.)
+// `an`/`bn` carry the first operand pair of the NEXT slot, requested before this slot's chain starts.
 // ------------------------------------------------------------------------------------------------
-template <class D, int TPW, int NACT, int NKS>
-VS_DEV void syrk_pass(d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW], int bufoff) {
-    const double* a[NACT];
-    const double* b[NACT];
+template <class D, int NKS>
+VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __restrict__ pb, double a0, double b0,
+                      const double* __restrict__ pan, const double* __restrict__ pbn, double& an, double& bn) {
+    double av[NKS], bv[NKS];
+    av[0] = a0;
+    bv[0] = b0;
 #pragma unroll
-    for (int q = 0; q < NACT; ++q) { a[q] = pa[q] + bufoff; b[q] = pb[q] + bufoff; }
-    double av[2][NACT], bv[2][NACT];
+    for (int ks = 1; ks < NKS; ++ks) { av[ks] = pa[ks * 4 * D::YS]; bv[ks] = pb[ks * 4 * D::YS]; }
+    an = pan[0];
+    bn = pbn[0];
 #pragma unroll
-    for (int q = 0; q < NACT; ++q) { av[0][q] = a[q][0]; bv[0][q] = b[q][0]; }
-    // each MFMA (64 cycles in the matrix pipe) is followed by the two operand loads of the same slot for the
-    // NEXT k-step: the loads issue in the shadow of the MFMA, so the pipe never waits for the load-issue burst
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-        for (int q = 0; q < NACT; ++q) {
-            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks & 1][q], bv[ks & 1][q], acc[q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NKS) {
-                av[(ks + 1) & 1][q] = a[q][(ks + 1) * 4 * D::YS];
-                bv[(ks + 1) & 1][q] = b[q][(ks + 1) * 4 * D::YS];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+    for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -294,20 +301,21 @@ VS_DEV void syrk_pass(d4 (&acc)[TPW], const double* const (&pa)[TPW], const doub
 // (LDS for the paper horizon, a global workspace for horizons whose factor does not fit LDS).
 // Returns non-zero if a pivot was not positive.
 // ------------------------------------------------------------------------------------------------
-// SPLIT: the panel is shared by several wavefronts with no communication.  Each takes the diagonal tile in its lanes
-// 0..15 (factored redundantly, bit-identical everywhere) and 48 of the rows below it in lanes 16..63, so every
-// wavefront runs the short one-slot stream.  The other wavefronts read the unfactored diagonal tile while wavefront
+// SPLIT: the panel is shared by several wavefronts with no communication.  Each takes the diagonal tile in lanes
+// 0..15 of its first slot (factored redundantly, bit-identical everywhere) and 64 NSLOT - 16 of the rows below it in
+// the remaining lanes (48 rows and the short one-slot stream wherever three wavefronts cover the panel).  The other wavefronts read the unfactored diagonal tile while wavefront
 // w = 0 works, so in SPLIT mode the factored diagonal tile is not stored here: it is handed back in `diag` (lanes
 // 0..15 of wavefront 0) and stored by the caller after the workgroup barrier that ends the panel step.
 template <class D, int NSLOT, int NPIV, bool SPLIT = false>
 VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16]) {
-    static_assert(!SPLIT || NSLOT == 1, "split panels are one-slot");
+    constexpr int RPW = 64 * NSLOT - 16;  // SPLIT: rows below the diagonal tile carried by one wavefront
     double* T[NSLOT];
     bool ok[NSLOT];
     double a[NSLOT][16];
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        const int r = SPLIT ? (lane < 16 ? 16 * p + lane : 16 * p + 48 * w + lane) : 16 * p + 64 * s + lane;
+        const int r = SPLIT ? ((s == 0 && lane < 16) ? 16 * p + lane : 16 * p + RPW * w + 64 * s + lane)
+                            : 16 * p + 64 * s + lane;
         ok[s] = r < D::NP;
         T[s] = Lb + tile_off<D>(ok[s] ? (r >> 4) : p, p) + (r & 15) * 17;  // rows beyond the matrix read an
 #pragma unroll                                                              // in-range tile and are never stored
@@ -365,24 +373,17 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
     return !(dmin > 0.0) || !(invs[NPIV - 1] == invs[NPIV - 1]);
 }
 
-template <class D, int TPW, int NKS, int NACT = TPW>
-VS_DEV void syrk_dispatch(int nact, d4 (&acc)[TPW], const double* const (&pa)[TPW], const double* const (&pb)[TPW],
-                          int bufoff) {
-    if constexpr (NACT >= 1) {
-        if (nact == NACT) syrk_pass<D, TPW, NACT, NKS>(acc, pa, pb, bufoff);
-        else syrk_dispatch<D, TPW, NKS, NACT - 1>(nact, acc, pa, pb, bufoff);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // P2 + P3 for wavefront W, straight-line: the panel index and the tile table are compile-time, so every
 // "does this tile take part" decision folds away and every LDS offset is an immediate.
 //   P2  input-cost terms (joint weights, throttle coupling, gradient row) are added to the SYRK
 //       accumulators in registers;
-//   P3  right-looking blocked Cholesky with a register-resident trailing matrix: a tile goes to LDS exactly
-//       once, when its tile column becomes the panel; wavefront 0 factors the panel (panel_factor), then
-//       every wavefront updates the tiles it owns with four v_mfma_f64_16x16x4_f64 per tile.
-// All four instantiations execute the same number of workgroup barriers.
+//   P3  right-looking blocked Cholesky with a register-resident trailing matrix AND a register-resident factor:
+//       a tile goes to LDS exactly once, when its tile column becomes the panel (ring of two columns, see
+//       Dims); the panel is factored in LDS (panel_factor); every wavefront updates the tiles it owns with four
+//       v_mfma_f64_16x16x4_f64 per tile and takes the finished tiles of the panel column it owns BACK into the
+//       accumulator registers that held them, where the back-substitution of P5 finds them.
+// All instantiations execute the same number of workgroup barriers.
 // ------------------------------------------------------------------------------------------------
 // X = L_pp^-1 of one factored diagonal tile by one wavefront: lane j carries column j (lanes >= 16 shadow), the
 // entries of L_pp and 1/L_ii are wave-uniform LDS broadcasts.  X is stored like a tile: X[i][j] at i*17 + j.
@@ -409,26 +410,37 @@ VS_DEV void tile_inverse(const double* __restrict__ Lpp, const double* __restric
     }
 }
 
-// G = X L_pq (16x16x16 on the matrix core, four k-steps) for one tile below a joint diagonal tile
-VS_DEV void scaled_tile(const double* __restrict__ X, const double* __restrict__ Lpq, double* __restrict__ G, int crow,
-                        int lrow) {
-    double la[4], lb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { la[ks] = X[lrow + 4 * ks]; lb[ks] = Lpq[crow + 4 * ks * 17]; }
-    d4 g = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], lb[ks], g, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) G[crow + 4 * r * 17] = g[r];
-}
+// Compile-time work lists of wavefront W: for every panel p the slots whose tile lies right of the panel column
+// (trailing update), and for every tile row r the slots whose tile (r, q), q < min(r, PVT), is kept in registers
+// after P3 (back-substitution).
+template <class D, int TPW, int W>
+struct WaveLists {
+    int ntrail[D::NT];
+    int trail[D::NT][TPW];
+    int nrow[D::NT];
+    int row[D::NT][TPW];
+    constexpr WaveLists() : ntrail{}, trail{}, nrow{}, row{} {
+        constexpr TileTab<D> tab{};
+        for (int p = 0; p < D::NT; ++p) {
+            for (int q = 0; q < TPW; ++q) {
+                const int t = q * D::NWAVES + W;
+                if (t < D::NTRI && tab.tj[t] > p) trail[p][ntrail[p]++] = q;
+                if (t < D::NTRI && tab.ti[t] == p && tab.tj[t] < p && tab.tj[t] < D::PVT) row[p][nrow[p]++] = q;
+            }
+        }
+    }
+};
 
 template <class D, int TPW, int W>
 VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
-                          double* __restrict__ sXinv, double* __restrict__ sG, int lane, int crow, int lrow) {
+                          double* __restrict__ sXinv, double* __restrict__ sW, double* __restrict__ dbgL, int lane,
+                          int crow, int lrow) {
     constexpr TileTab<D> tab{};
+    constexpr WaveLists<D, TPW, W> wl{};
     using S = Smem<D>;
-    constexpr int PVT = D::NU >> 4;
+    constexpr int PVT = D::PVT;
+    constexpr int GL = D::NZ & 15;  // local row of the gradient row (row NZ) in the last tile row
     // ---- P2
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -445,106 +457,158 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
     for (int q = 0; q < TPW; ++q) {
         const int t = q * D::NWAVES + W;
         if (t < D::NTRI && tab.tj[t] == 0) {
-            double* T = sM + tile_off<D>(tab.ti[t], 0) + crow;
+            double* T = sM + tile_off_c<D>(tab.ti[t], 0) + crow;
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
         }
     }
-    if constexpr (!D::L_IN_LDS) __threadfence_block();
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < D::NT; ++p) {
-        // rows under the diagonal tile and the wavefronts that share the panel (48 rows each, see panel_factor)
+        // rows under the diagonal tile and the wavefronts that share the panel (see panel_factor): one-slot streams of 48
+        // rows wherever NWAVES - 1 wavefronts cover the panel, PANEL_SLOTS-slot streams for the tall panels of long horizons
         const int below = D::NP - 16 * p - 16;
-        const int nshare = below <= 48 ? 1 : (below + 47) / 48;
+        const bool one_slot = (below + 47) / 48 <= D::NWAVES - 1;
+        const int rpw = one_slot ? 48 : 64 * D::PANEL_SLOTS - 16;
+        const int nshare = below <= rpw ? 1 : (below + rpw - 1) / rpw;
         double diag[16];  // factored diagonal tile of a shared panel (wavefront 0, lanes 0..15), stored after the barrier
         {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
-            static_assert((D::NP - 16 + 47) / 48 <= D::NWAVES - 1, "panel 0 leaves one wavefront for the side work");
             if (p == D::NT - 1) {
                 if (W == 0 && panel_factor<D, 1, NPIV_LAST>(sM, sInvD, p, lane, 0, diag) && lane == 0) sFlags[0] = 1;
             } else if (W < nshare) {
-                const int bad = panel_factor<D, 1, 16, true>(sM, sInvD, p, lane, W, diag);
+                int bad;
+                if (one_slot) bad = panel_factor<D, 1, 16, true>(sM, sInvD, p, lane, W, diag);
+                else bad = panel_factor<D, D::PANEL_SLOTS, 16, true>(sM, sInvD, p, lane, W, diag);
                 if (W == 0 && bad && lane == 0) sFlags[0] = 1;
             }
         }
-        if constexpr (S::FASTSWEEP) {
-            // wavefronts without panel rows: one inverts the diagonal tile finished one panel ago (the last wavefront
-            // while wavefront 1 still has panel rows), wavefronts 2 and 3 scale the tiles left of the one finished two
-            // panels ago
-            if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p >= 1 && p - 1 <= S::NJT)
-                tile_inverse<D>(sM + tile_off<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
-            if ((W == 2 || W == 3) && p >= 3 && p - 2 < S::NJT) {
-                const int pr = p - 2;
-#pragma unroll
-                for (int q = W - 2; q < pr; q += 2)
-                    scaled_tile(sXinv + pr * D::TS, sM + tile_off<D>(pr, q), sG + (pr * (pr - 1) / 2 + q) * D::TS, crow,
-                                lrow);
-            }
-        }
-        if constexpr (!D::L_IN_LDS) __threadfence_block();  // panel lives in global memory: order it for the other waves
+        // a wavefront without panel rows inverts the diagonal tile finished one panel ago (its ring slot is intact
+        // until the update of THIS panel hands column p+1 over): X_0..X_PVT for P5 and the dual box QP
+        if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p >= 1 && p - 1 < S::NXT)
+            tile_inverse<D>(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
         __syncthreads();
-        {
-            if (W == 0 && p < D::NT - 1 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
-                double* Tpp = sM + tile_off<D>(p, p) + lane * 17;
+        if (W == 0 && p < D::NT - 1 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
+            double* Tpp = sM + tile_off_c<D>(p, p) + lane * 17;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) Tpp[c] = diag[c];
+            for (int c = 0; c < 16; ++c) Tpp[c] = diag[c];
+            if (dbgL != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c <= lane) dbgL[size_t(16 * p + lane) * D::NP + 16 * p + c] = diag[c];
             }
         }
-        if constexpr (TPW > 12) {
-            // long horizons (30 tiles per wavefront): tile by tile, operands straight from the (L2-resident) workspace
-            if (p + 1 < D::NT) {
+        if (p + 1 < D::NT) {
+            // trailing update M_ij -= L_ip L_jp^T for the owned tiles right of the panel; the operands of the next
+            // tile are requested before the four matrix-core instructions of the current one
+            double la[2][4], lb[2][4];
+            if (wl.ntrail[p] > 0) {
+                const int t = wl.trail[p][0] * D::NWAVES + W;
+                const double* Lip = sM + tile_off_c<D>(tab.ti[t], p) + lrow;
+                const double* Ljp = sM + tile_off_c<D>(tab.tj[t], p) + lrow;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { la[0][ks] = -Lip[4 * ks]; lb[0][ks] = Ljp[4 * ks]; }
+            }
+#pragma unroll
+            for (int a = 0; a < TPW; ++a) {
+                if (a < wl.ntrail[p]) {
+                    const int q = wl.trail[p][a];
+                    const int t = q * D::NWAVES + W;
+                    if (a + 1 < wl.ntrail[p]) {
+                        const int tn = wl.trail[p][a + 1] * D::NWAVES + W;
+                        const double* Lip = sM + tile_off_c<D>(tab.ti[tn], p) + lrow;
+                        const double* Ljp = sM + tile_off_c<D>(tab.tj[tn], p) + lrow;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) { la[(a + 1) & 1][ks] = -Lip[4 * ks]; lb[(a + 1) & 1][ks] = Ljp[4 * ks]; }
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[a & 1][ks], lb[a & 1][ks], acc[q], 0, 0, 0);
+                    if (tab.tj[t] == p + 1) {  // this tile column is the next panel: hand it to LDS
+                        double* T = sM + tile_off_c<D>(tab.ti[t], p + 1) + crow;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                    }
+                }
+            }
+            // finished tiles of panel column p come back into the registers that held them (columns of the throttle
+            // corner stay in LDS); the gradient row -> right-hand side y = -L^-1 g of the back-substitution
+            if (p < PVT) {
 #pragma unroll
                 for (int q = 0; q < TPW; ++q) {
                     const int t = q * D::NWAVES + W;
-                    if (t < D::NTRI && tab.tj[t] > p) {
-                        const double* Lip = sM + tile_off<D>(tab.ti[t], p) + lrow;
-                        const double* Ljp = sM + tile_off<D>(tab.tj[t], p) + lrow;
-                        double la1[4], lb1[4];
+                    if (t < D::NTRI && tab.tj[t] == p && tab.ti[t] > p) {
+                        const double* T = sM + tile_off_c<D>(tab.ti[t], p) + crow;
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) { la1[ks] = -Lip[4 * ks]; lb1[ks] = Ljp[4 * ks]; }
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la1[ks], lb1[ks], acc[q], 0, 0, 0);
-                        if (tab.tj[t] == p + 1) {
-                            double* T = sM + tile_off<D>(tab.ti[t], p + 1) + crow;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
-                        }
+                        for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
+                        if (tab.ti[t] == D::NT - 1 && (lane >> 4) == (GL & 3)) sW[16 * p + (lane & 15)] = -acc[q][GL >> 2];
                     }
                 }
-                __threadfence_block();
-                __syncthreads();
             }
-        } else if (p + 1 < D::NT) {
-            // trailing update M_ij -= L_ip L_jp^T for the tiles right of the panel: operands first, then the chains
-            double la[TPW][4], lb[TPW][4];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P5 for wavefront W: back-substitution L^T z = w from the REGISTER-resident factor, tile row by tile row from
+// the bottom.  z_r is known (throttle rows: sZ; joint rows: z_r = X_r^T (w_r - u_r), every wavefront forms it
+// redundantly and bit-identically, so no barrier separates it from its use); every owned tile (r, q) then adds
+// L_rq^T z_r to this wavefront's private partial sum u[q] (fixed summation order -> deterministic); one
+// workgroup barrier per tile row.
+// ------------------------------------------------------------------------------------------------
+template <class D, int TPW, int W>
+VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, double* __restrict__ sZ,
+                         const double* __restrict__ sXinv, double* __restrict__ sU, double* __restrict__ sZw, int lane) {
+    constexpr WaveLists<D, TPW, W> wl{};
+    constexpr TileTab<D> tab{};
+    constexpr int PVT = D::PVT;
+    double* myU = sU + W * D::NP;
+    double* myD = sZw + W * 32;
+    double* myZ = myD + 16;
+    const int j = lane & 15, g4 = lane >> 4;
+    for (int i = lane; i < 16 * PVT; i += 64) myU[i] = 0.0;  // read by the others only after the first barrier below
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                const int t = q * D::NWAVES + W;
-                if (t < D::NTRI && tab.tj[t] > p) {
-                    const double* Lip = sM + tile_off<D>(tab.ti[t], p) + lrow;
-                    const double* Ljp = sM + tile_off<D>(tab.tj[t], p) + lrow;
+    for (int r = D::NT - 1; r >= 0; --r) {
+        const double* zsrc = sZ + 16 * r;
+        if (r < PVT) {
+            double d = sW[16 * r + j];
+            double usum = sU[16 * r + j];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { la[q][ks] = -Lip[4 * ks]; lb[q][ks] = Ljp[4 * ks]; }
-                }
+            for (int w = 1; w < D::NWAVES; ++w) usum += sU[w * D::NP + 16 * r + j];
+            d -= usum;
+            if (lane < 16) myD[j] = d;
+            const double* X = sXinv + r * D::TS + j;
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {   // z_j = sum_i X[i][j] d_i; myD[i]: uniform address, LDS broadcast
+                z0 = fma(X[i * 17], myD[i], z0);
+                z1 = fma(X[(i + 1) * 17], myD[i + 1], z1);
             }
-#pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                const int t = q * D::NWAVES + W;
-                if (t < D::NTRI && tab.tj[t] > p) {
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q][ks], lb[q][ks], acc[q], 0, 0, 0);
-                }
+            const double z = z0 + z1;
+            if (lane < 16) {
+                myZ[j] = z;
+                if (W == 0) sZ[16 * r + j] = z;
             }
+            zsrc = myZ;
+        }
+        if (r > 0) {
+            if (wl.nrow[r] > 0) {
+                double zz[4];
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) {
-                const int t = q * D::NWAVES + W;
-                if (t < D::NTRI && tab.tj[t] == p + 1) {  // this tile column is the next panel: hand it to LDS
-                    double* T = sM + tile_off<D>(tab.ti[t], p + 1) + crow;
+                for (int i = 0; i < 4; ++i) zz[i] = zsrc[g4 + 4 * i];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                for (int a = 0; a < TPW; ++a) {
+                    if (a < wl.nrow[r]) {
+                        const int q = wl.row[r][a];
+                        const int t = q * D::NWAVES + W;
+                        double part = acc[q][0] * zz[0];
+#pragma unroll
+                        for (int i = 1; i < 4; ++i) part = fma(acc[q][i], zz[i], part);
+                        part += __shfl_xor(part, 16);
+                        part += __shfl_xor(part, 32);
+                        if (lane < 16) myU[16 * tab.tj[t] + j] += part;
+                    }
                 }
             }
             __syncthreads();
@@ -598,6 +662,8 @@ VS_DEV double small_spd_solve(const double* __restrict__ sP, unsigned long long 
 
 // size dispatch for small_spd_solve (one straight-line instantiation per size)
 constexpr int SMALL_SOLVE_MAX = 12;
+// block principal pivoting: non-improving block steps tolerated before the least-index fallback (the oracle's value)
+constexpr int AS_PATIENCE = 10;
 template <int NVS, int K = SMALL_SOLVE_MAX>
 VS_DEV double small_spd_solve_n(int k, const double* __restrict__ sP, unsigned long long mask, double rhs, int lane, int& bad) {
     if constexpr (K == 1) {
@@ -634,12 +700,11 @@ VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec,
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
 // `stamps` (its own buffer, never read by the kernel).  The shipped instantiation has STAMPS = false.
 template <class D, bool STAMPS>
-__global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
+__global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* __restrict__ xout, double* __restrict__ fmout,
                                                          int* __restrict__ status_out, int* __restrict__ iters_out,
                                                          double* __restrict__ dbgM, double* __restrict__ dbgL,
-                                                         unsigned long long* __restrict__ stamps,
-                                                         double* __restrict__ gLws) {
+                                                         unsigned long long* __restrict__ stamps) {
 #define VS_STAMP(i)                                                                         \
     do {                                                                                    \
         if constexpr (STAMPS) {                                                             \
@@ -679,20 +744,18 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     double* sF = smem + S::oF;
     double* sDt = smem + S::oDt;
     int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);  // [0] numerical failure, [1] status, [2] iters, [3] bound violated
-    double* sEllV = smem + S::oEllV;
-    int* sEllC = reinterpret_cast<int*>(smem + S::oEllC);
     double* sY = smem + S::oY;
-    double* sM = smem + S::oM;  // tile storage of the factor when it fits LDS
-    double* sXinv = smem + S::oXinv;  // inverses of the joint diagonal tiles, scaled joint tiles (see Smem)
-    double* sG = smem + S::oG;
+    double* Lb = smem + S::oM;        // tile storage: ring of two panel columns + throttle corner (see Dims)
+    double* sXinv = smem + S::oXinv;  // inverses of the joint diagonal tiles and of the first throttle tile
+    double* sQP = smem + S::oQP;      // dual box QP work arrays
+    double* sU = smem + S::oU;        // register back-substitution: per-wavefront partial sums, scratch
+    double* sZw = smem + S::oZw;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
     const int inst = blockIdx.x;
     if (inst >= batch) return;
-    // tile storage of the factor: LDS, or this instance's slice of the global workspace
-    double* Lb = D::L_IN_LDS ? sM : gLws + size_t(inst) * D::L_WORKSPACE_DOUBLES;
 
     // tiles of the lower triangle are dealt round-robin to the wavefronts: tile t -> wave t % NWAVES, slot t / NWAVES.
     // The (wave-uniform) coordinates come from a table in constant memory; requested first so that the scalar loads'
@@ -732,22 +795,60 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
 #pragma unroll
     for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
 
+    // P1a: jet sub-system.  The model is a cascade (jets -> momenta -> CoM / RPY -> integrators) and the jets are
+    // decoupled from each other, so of the condensed columns only the throttle columns (one jet each) and the affine
+    // column (four) carry a non-zero thrust sensitivity: NV + 4 two-state recursions over the whole horizon, one per
+    // lane, whose thrust trajectories T_k go to LDS.  The momentum recursion below then needs one scalar per column and
+    // stage instead of eight jet states, their input vectors and twelve coefficients in every thread -- which is what
+    // brings P1 under the 256 registers a wavefront gets when two workgroups share a CU.   (systemDynamicsVSMPC.cpp:384-429)
+    constexpr int NJROW = D::NV + NTH + 1, ZROW = D::NV + NTH;  // + an all-zero row for the joint and padding columns
+    double* sJetT = sXinv;                    // [NJROW][N]; the X tiles are not written before P3
+    double* sGA = sJetT + NJROW * D::N;       // [2][N][3]: A_mom T_k of the affine column, per half
+    static_assert(D::NV + NTH <= 64 && NJROW * D::N + 6 * D::N <= S::NXT * D::TS, "jet trajectories fit the X region");
+    if (wave == D::NWAVES - 1) {
+        if (lane < D::NV + NTH) {
+            const bool affl = lane >= D::NV;
+            const int i = affl ? lane - D::NV : (lane & 3);
+            const int blk = affl ? -1 : v_block_of_internal<D>(lane);
+            const double jon = sA[(12 + i) * NX + 16 + i], ja = sA[(16 + i) * NX + 12 + i], jb = sA[(16 + i) * NX + 16 + i];
+            const double c12 = sC[12 + i], c16 = sC[16 + i], b12 = sBt[(12 + i) * NTH + i], b16 = sBt[(16 + i) * NTH + i];
+            const double t0 = sIn[VSMPC_IN_X0 + 12 + i], td0 = sIn[VSMPC_IN_X0 + 16 + i];
+            const double bT = affl ? c12 : b12, bTd = affl ? c16 : b16;
+            double T = affl ? t0 : 0.0, Td = affl ? td0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < D::N; ++k) {
+                sJetT[lane * D::N + k] = T;   // the momentum rate of stage k sees T_k (explicit Euler)
+                const double mT = (affl || throttle_block_of_stage<D>(k) == blk) ? 1.0 : 0.0;
+                const double dT = fma(jon, Td, mT * bT);
+                const double dTd = fma(ja, T, fma(jb, Td, mT * bTd));
+                const double dt = sDt[k];
+                T = fma(dt, dT, T);
+                Td = fma(dt, dTd, Td);
+            }
+        }
+        for (int k = lane; k < D::N; k += 64) sJetT[ZROW * D::N + k] = 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * D::N; e += D::BLOCK) {
+        const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3, row = (h ? 9 : 3) + r;
+        double g = 0.0;
+#pragma unroll
+        for (int c = 0; c < NTH; ++c) g = fma(sA[row * NX + 12 + c], sJetT[(D::NV + c) * D::N + k], g);
+        sGA[e] = g;
+    }
+    __syncthreads();
+
     {
-        // thread (half, col): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy);
-        // both carry the jet states (T, Tdot) of their column.  Same code, different coefficient rows.
+        // P1b: thread (half, c): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy) of the
+        // condensed columns c, c + 128, ... (CPT of them; one at the paper horizon).  Same code, different coefficient rows.
+        constexpr int CPT = D::CPT;
         const int half = wave / (D::NWAVES / 2);  // scalar
-        const int col = tid % D::PCOLS;
         const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
         const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
-        int kind = 3, blk = 0, comp = 0;  // 0 joint column, 1 throttle column, 2 affine column, 3 pad
-        if (col < D::NU) { kind = 0; blk = col >> 3; comp = col & 7; }
-        else if (col < D::NZ) { kind = 1; blk = v_block_of_internal<D>(col - D::NU); comp = (col - D::NU) & 3; }
-        else if (col == D::NZ) { kind = 2; }
 
-        // coefficient rows of this half.  Paper horizon: loaded once, they stay in registers for all passes.  Long
-        // horizons (two wavefronts per SIMD, 256 registers each, 15 accumulator tiles): reloaded at the top of every
-        // pass so that they are dead during the matrix-core section instead of being spilled to scratch.
-        double M1[9], Sk[9], Am[12], jon[4], ja[4], jb[4];
+        // coefficient rows of this half: wave-uniform LDS broadcasts, re-read at the top of every pass so that they are
+        // dead during the matrix-core section (the accumulator tiles stay in registers for the whole of P1..P5)
+        double M1[9], Sk[9], Ce[3];
         auto load_coeffs = [&]() {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -756,131 +857,115 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                     M1[3 * r + c] = sA[(xr0 + r) * NX + hr0 + c];
                     Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) Am[4 * r + c] = sA[(hr0 + r) * NX + 12 + c];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                jon[i] = sA[(12 + i) * NX + 16 + i];
-                ja[i] = sA[(16 + i) * NX + 12 + i];
-                jb[i] = sA[(16 + i) * NX + 16 + i];
+                Ce[r] = sC[er0 + r];
             }
         };
-        if constexpr (D::L_IN_LDS) load_coeffs();
         double sqx[3], sqh[3], sqe[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { sqx[r] = cfg.sq[yx0 + r]; sqh[r] = cfg.sq[yh0 + r]; sqe[r] = cfg.sq[ye0 + r]; }
-        const double aff = kind == 2 ? 1.0 : 0.0;
-        // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step and the Y
-        // buffer enter as immediate offsets of ds_read_b64
+        // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step enters as an
+        // immediate offset of ds_read_b64
         const int ylane = (lane >> 4) * D::YS + (lane & 15);
         constexpr int NPASS = (D::N + 1) / 2;
-        constexpr int BUFSZ = S::YROWS * D::YS;
-        if constexpr (STAMPS) { t_mark = stamp_t1; VS_TOC(3); }  // P1 set-up (coefficient loads)
+        if constexpr (STAMPS) { t_mark = stamp_t1; VS_TOC(3); }  // P1 set-up
 
-        // One sweep = the sensitivity recursion over the whole horizon + the SYRK into the accumulator slots
-        // [S0, S1) of this wavefront.  The paper horizon runs one sweep over all slots.  Long horizons run two (the
-        // recursion is cheap next to a SYRK that spills): with 15 accumulator tiles live the matrix-core stream does
-        // not fit the 256 registers a wavefront of a 512-thread workgroup gets.
-        auto sweep = [&](auto s0c, auto s1c) {
-        constexpr int S0 = decltype(s0c)::value, S1 = decltype(s1c)::value, NSL = S1 - S0;
-        double xs[3], hs[3], es[3], Ts[4], Tds[4];
-        double bh[3], ce[3], bT[4], bTd[4];
-        // unconditional loads (every address is valid for every column), selected afterwards: conditional loads
-        // become branches and the LDS latencies add up instead of overlapping
-        const int jc = comp & 7, tc = comp & 3;
-        const bool aff_col = kind == 2, jnt_col = kind == 0, thr_col = kind == 1;
+        // The sensitivity recursion over the whole horizon + the SYRK into all accumulator slots of this wavefront.
+        // Y is single-buffered (two barriers per pass): the second buffer is what kept a second workgroup off the CU,
+        // and a co-resident workgroup fills the recursion's bubbles far better than the look-ahead did.
+        int col[CPT], kind[CPT], blk[CPT];   // kind: 0 joint column, 1 throttle column, 2 affine column, 3 pad
+        double aff[CPT], xs[CPT][3], hs[CPT][3], es[CPT][3], bh[CPT][3], amt[CPT][3];
+        const double* jetT[CPT];
+        const double* gaT = sGA + half * 3 * D::N;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double x0 = sIn[VSMPC_IN_X0 + xr0 + r], h0 = sIn[VSMPC_IN_X0 + hr0 + r], e0 = sIn[VSMPC_IN_X0 + er0 + r];
-            const double bj = sBj[(hr0 + r) * NJ + jc], ch = sC[hr0 + r], cee = sC[er0 + r];
-            xs[r] = aff_col ? x0 : 0.0;
-            hs[r] = aff_col ? h0 : 0.0;
-            es[r] = aff_col ? e0 : 0.0;
-            bh[r] = jnt_col ? bj : (aff_col ? ch : 0.0);
-            ce[r] = aff_col ? cee : 0.0;
+        for (int cc = 0; cc < CPT; ++cc) {
+            const int c = cc * D::PCOLS + tid % D::PCOLS;
+            int comp = 0;
+            col[cc] = c;
+            kind[cc] = 3;
+            blk[cc] = 0;
+            if (c < D::NU) { kind[cc] = 0; blk[cc] = c >> 3; comp = c & 7; }
+            else if (c < D::NZ) { kind[cc] = 1; blk[cc] = v_block_of_internal<D>(c - D::NU); comp = (c - D::NU) & 3; }
+            else if (c == D::NZ) { kind[cc] = 2; }
+            // unconditional loads (every address is valid for every column), selected afterwards: conditional loads
+            // become branches and the LDS latencies add up instead of overlapping
+            const int jc = comp & 7, tc = comp & 3;
+            const bool aff_col = kind[cc] == 2, jnt_col = kind[cc] == 0, thr_col = kind[cc] == 1;
+            aff[cc] = aff_col ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double x0 = sIn[VSMPC_IN_X0 + xr0 + r], h0 = sIn[VSMPC_IN_X0 + hr0 + r], e0 = sIn[VSMPC_IN_X0 + er0 + r];
+                const double bj = sBj[(hr0 + r) * NJ + jc], ch = sC[hr0 + r], at = sA[(hr0 + r) * NX + 12 + tc];
+                xs[cc][r] = aff_col ? x0 : 0.0;
+                hs[cc][r] = aff_col ? h0 : 0.0;
+                es[cc][r] = aff_col ? e0 : 0.0;
+                bh[cc][r] = jnt_col ? bj : (aff_col ? ch : 0.0);
+                amt[cc][r] = thr_col ? at : 0.0;  // thrust map column of the one jet this throttle column drives
+            }
+            // this column's thrust trajectory: a throttle column's own jet, the zero row otherwise (the affine column's
+            // four jets enter through sGA)
+            jetT[cc] = sJetT + (thr_col ? c - D::NU : ZROW) * D::N;
         }
+        const double* pa[TPW];
+        const double* pb[TPW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double t0 = sIn[VSMPC_IN_X0 + 12 + i], td0 = sIn[VSMPC_IN_X0 + 16 + i];
-            const double b12 = sBt[(12 + i) * NTH + i], b16 = sBt[(16 + i) * NTH + i], c12 = sC[12 + i], c16 = sC[16 + i];
-            Ts[i] = aff_col ? t0 : 0.0;
-            Tds[i] = aff_col ? td0 : 0.0;
-            bT[i] = thr_col ? (i == tc ? b12 : 0.0) : (aff_col ? c12 : 0.0);
-            bTd[i] = thr_col ? (i == tc ? b16 : 0.0) : (aff_col ? c16 : 0.0);
-        }
-        d4 a[NSL];
-        const double* pa[NSL];
-        const double* pb[NSL];
-        int ts[NSL];
-#pragma unroll
-        for (int q = 0; q < NSL; ++q) {
-            a[q] = d4{0.0, 0.0, 0.0, 0.0};
-            pa[q] = sY + ylane + 16 * ti[S0 + q];
-            pb[q] = sY + ylane + 16 * tj[S0 + q];
-            ts[q] = tstart[S0 + q];
+        for (int q = 0; q < TPW; ++q) {
+            pa[q] = sY + ylane + 16 * ti[q];
+            pb[q] = sY + ylane + 16 * tj[q];
         }
 #pragma unroll 1
         for (int m = 0; m < NPASS; ++m) {
-            const int bufoff = (S::NYBUF == 2) ? (m & 1) * BUFSZ : 0;
-            double* Yb = sY + bufoff;
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
-            if constexpr (!D::L_IN_LDS) load_coeffs();
-            // both nodes unrolled when registers allow (their loads and chains interleave); long horizons keep a loop
-#pragma clang loop unroll_count(D::L_IN_LDS ? 2 : 1)
+            load_coeffs();
+#pragma unroll
             for (int par = 0; par < 2; ++par) {
                 if (par >= nnodes) break;  // the last pass of an odd horizon has one node
                 const int k = 2 * m + par;  // stage k -> node k+1
                 const double dt = sDt[k];
-                // reference of this node (affine column only; column map costsVSMPC.cpp:191-200), requested before the
-                // recursion so that the LDS latency is spent under it
+                // reference of this node (affine column only; column map costsVSMPC.cpp:191-200) and the affine column's
+                // thrust forcing, requested before the recursion so that the LDS latency is spent under it
                 const int rc = k < D::NS ? 0 : k - D::NS;
                 const double* xr = sIn + VSMPC_IN_XREF + rc * 12;  // uniform address: LDS broadcast
-                double xrx[3], xrh[3];
+                double xrx[3], xrh[3], ga[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) { xrx[r] = xr[yx0 + r]; xrh[r] = xr[yh0 + r]; }
-                const bool actJ = (kind == 0 && joint_block_of_stage<D>(k) == blk) || kind == 2;
-                const bool actT = (kind == 1 && throttle_block_of_stage<D>(k) == blk) || kind == 2;
-                // input activity as 0/1 factors inside the multiply-adds (a 64-bit select costs two instructions);
-                // the jet part of the momentum rate is a chain of its own so that more chains are in flight
-                const double mJ = actJ ? 1.0 : 0.0, mT = actT ? 1.0 : 0.0;
-                double dx[3], dh[3], de[3], dT[4], dTd[4];
+                for (int r = 0; r < 3; ++r) { xrx[r] = xr[yx0 + r]; xrh[r] = xr[yh0 + r]; ga[r] = gaT[3 * k + r]; }
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    double a0 = M1[3 * r] * hs[0], a1 = mJ * bh[r], a2 = Am[4 * r] * Ts[0];
+                for (int cc = 0; cc < CPT; ++cc) {
+                    const double tk = jetT[cc][k];
+                    const bool actJ = (kind[cc] == 0 && joint_block_of_stage<D>(k) == blk[cc]) || kind[cc] == 2;
+                    // input activity as a 0/1 factor inside the multiply-adds (a 64-bit select costs two instructions)
+                    const double mJ = actJ ? 1.0 : 0.0;
+                    double dx[3], dh[3], de[3];
 #pragma unroll
-                    for (int c = 1; c < 3; ++c) a0 = fma(M1[3 * r + c], hs[c], a0);
+                    for (int r = 0; r < 3; ++r) {
+                        double a0 = M1[3 * r] * hs[cc][0], a1 = mJ * bh[cc][r], a2 = aff[cc] * ga[r];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) a1 = fma(Sk[3 * r + c], hs[c], a1);
+                        for (int c = 1; c < 3; ++c) a0 = fma(M1[3 * r + c], hs[cc][c], a0);
 #pragma unroll
-                    for (int c = 1; c < 4; ++c) a2 = fma(Am[4 * r + c], Ts[c], a2);
-                    dx[r] = a0;
-                    dh[r] = a1 + a2;
-                    de[r] = xs[r] + ce[r];
-                }
+                        for (int c = 0; c < 3; ++c) a1 = fma(Sk[3 * r + c], hs[cc][c], a1);
+                        a2 = fma(amt[cc][r], tk, a2);
+                        dx[r] = a0;
+                        dh[r] = a1 + a2;
+                        de[r] = fma(aff[cc], Ce[r], xs[cc][r]);
+                    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dT[i] = fma(jon[i], Tds[i], mT * bT[i]);
-                    dTd[i] = fma(ja[i], Ts[i], fma(jb[i], Tds[i], mT * bTd[i]));
-                }
+                    for (int r = 0; r < 3; ++r) { xs[cc][r] += dt * dx[r]; hs[cc][r] += dt * dh[r]; es[cc][r] += dt * de[r]; }
+                    // Y rows of this node: sqrt(Q) (S_k - xref_k on the affine column); column map costsVSMPC.cpp:191-200
+                    if (CPT == 1 || col[cc] < D::NP) {
+                        double* Yn = sY + 18 * par * D::YS + col[cc];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) { xs[r] += dt * dx[r]; hs[r] += dt * dh[r]; es[r] += dt * de[r]; }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { Ts[i] += dt * dT[i]; Tds[i] += dt * dTd[i]; }
-                // Y rows of this node: sqrt(Q) (S_k - xref_k on the affine column); column map costsVSMPC.cpp:191-200
-                double* Yn = Yb + 18 * par * D::YS + col;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const double vx = fma(-aff, xrx[r], xs[r]);  // aff = 1 on the affine column, else 0
-                    const double vh = fma(-aff, xrh[r], hs[r]);
-                    Yn[(yx0 + r) * D::YS] = sqx[r] * vx;
-                    Yn[(yh0 + r) * D::YS] = sqh[r] * vh;
-                    Yn[(ye0 + r) * D::YS] = sqe[r] * es[r];
+                        for (int r = 0; r < 3; ++r) {
+                            const double vx = fma(-aff[cc], xrx[r], xs[cc][r]);  // aff = 1 on the affine column, else 0
+                            const double vh = fma(-aff[cc], xrh[r], hs[cc][r]);
+                            Yn[(yx0 + r) * D::YS] = sqx[r] * vx;
+                            Yn[(yh0 + r) * D::YS] = sqh[r] * vh;
+                            Yn[(ye0 + r) * D::YS] = sqe[r] * es[cc][r];
+                        }
+                    }
                 }
             }
             if (nnodes == 1)  // rows 18,19 of the last, single-node pass (k-step 4 reads rows 16..19)
-                for (int i = tid; i < 2 * D::YS; i += D::BLOCK) Yb[18 * D::YS + i] = 0.0;
+                for (int i = tid; i < 2 * D::YS; i += D::BLOCK) sY[18 * D::YS + i] = 0.0;
             VS_TOC(0);
             __syncthreads();
             VS_TOC(1);
@@ -889,97 +974,73 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             const int last_stage = 2 * m + nnodes - 1;
             int nact = 0;  // scalar: the table is sorted by first stage, so the active slots are a prefix
 #pragma unroll
-            for (int q = 0; q < NSL; ++q) nact += (last_stage >= ts[q]) ? 1 : 0;
-            static_assert(NSL <= 12, "a sweep keeps at most 12 accumulator tiles per wavefront");
-            if (nnodes == 2) syrk_dispatch<D, NSL, 9>(nact, a, pa, pb, bufoff);
-            else syrk_dispatch<D, NSL, 5>(nact, a, pa, pb, bufoff);
+            for (int q = 0; q < TPW; ++q) nact += (last_stage >= tstart[q]) ? 1 : 0;
+            {
+                double a0 = pa[0][0], b0 = pb[0][0], an = 0.0, bn = 0.0;
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    if (q < nact) {  // scalar branch per slot
+                        const double* pan = pa[q + 1 < TPW ? q + 1 : q];
+                        const double* pbn = pb[q + 1 < TPW ? q + 1 : q];
+                        if (nnodes == 2) syrk_slot<D, 9>(acc[q], pa[q], pb[q], a0, b0, pan, pbn, an, bn);
+                        else syrk_slot<D, 5>(acc[q], pa[q], pb[q], a0, b0, pan, pbn, an, bn);
+                        a0 = an;
+                        b0 = bn;
+                    }
+                }
+            }
             VS_TOC(2);
-            // double-buffered Y: one barrier per pass (the next pass writes the other buffer); single buffer: two
-            if constexpr (S::NYBUF == 1) __syncthreads();
-        }
-#pragma unroll
-        for (int q = 0; q < NSL; ++q) acc[S0 + q] = a[q];
-        };  // sweep
-
-        if constexpr (TPW <= 12) {
-            sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, TPW>{});
-        } else {
-            constexpr int SH = (TPW + 1) / 2;
-            const int crow0 = (lane >> 4) * 17 + (lane & 15);
-            sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, SH>{});
-            // park the first half in this instance's workspace slice (each lane re-reads only what it wrote)
-#pragma unroll
-            for (int q = 0; q < SH; ++q) {
-                double* T = Lb + tile_off<D>(ti[q], tj[q]) + crow0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
-            }
-            if constexpr (S::NYBUF == 2) __syncthreads();  // the second sweep starts over with Y buffer 0
-            sweep(std::integral_constant<int, SH>{}, std::integral_constant<int, TPW>{});
-#pragma unroll
-            for (int q = 0; q < SH; ++q) {
-                const double* T = Lb + tile_off<D>(ti[q], tj[q]) + crow0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
-            }
+            __syncthreads();  // single Y buffer: the next pass overwrites it
         }
         VS_TIC();
     }
-    __syncthreads();
     VS_STAMP(2);
 
     // ---------------------------------------------------------------- P2 + P3 (wave-specialised, see cholesky_wave)
-    constexpr int PVT = D::NU >> 4;  // first tile row that contains a throttle row
+    constexpr int PVT = D::PVT;  // first tile row that contains a throttle row
     const int crow = (lane >> 4) * 17 + (lane & 15);  // C/D fragment: row (lane>>4)+4r, column lane&15
     const int lrow = (lane & 15) * 17 + (lane >> 4);  // A/B fragment: row lane&15, k = lane>>4
-    if (dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation
-        d4 tmp[TPW];
+    double* dbgLi = dbgL != nullptr ? dbgL + size_t(inst) * D::NP * D::NP : nullptr;
+    if (dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            tmp[q] = acc[q];
             if (q * D::NWAVES + wave < D::NTRI) {
+                d4 tmp = acc[q];
                 if (ti[q] == tj[q] || ti[q] >= PVT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        tmp[q][r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * ti[q] + (lane >> 4) + 4 * r,
-                                                        16 * tj[q] + (lane & 15));
+                        tmp[r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * ti[q] + (lane >> 4) + 4 * r,
+                                                     16 * tj[q] + (lane & 15));
                 }
-                double* T = Lb + tile_off<D>(ti[q], tj[q]) + crow;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T[4 * r * 17] = tmp[q][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = 16 * ti[q] + (lane >> 4) + 4 * r, gc = 16 * tj[q] + (lane & 15);
+                    if (gc <= gr) dbgM[size_t(inst) * D::NP * D::NP + size_t(gr) * D::NP + gc] = tmp[r];
+                }
             }
         }
-        if constexpr (!D::L_IN_LDS) __threadfence_block();
-        __syncthreads();
-        for (int e = tid; e < D::NP * D::NP; e += D::BLOCK) {
-            const int gr = e / D::NP, gc = e % D::NP;
-            dbgM[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? Lb[lower_at<D>(gr, gc)] : 0.0;
-        }
-        __syncthreads();
     }
     VS_STAMP(3);
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-        case 3: cholesky_wave<D, TPW, 3>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-        default:
-            if constexpr (D::NWAVES > 4) {
-                switch (wave) {
-                    case 4: cholesky_wave<D, TPW, 4>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-                    case 5: cholesky_wave<D, TPW, 5>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-                    case 6: cholesky_wave<D, TPW, 6>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-                    default: cholesky_wave<D, TPW, 7>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sG, lane, crow, lrow); break;
-                }
-            }
-            break;
+        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        default: cholesky_wave<D, TPW, 3>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
     }
-    if (dbgL != nullptr) {
-        for (int e = tid; e < D::NP * D::NP; e += D::BLOCK) {
-            const int gr = e / D::NP, gc = e % D::NP;
-            dbgL[size_t(inst) * D::NP * D::NP + e] = gc <= gr ? Lb[lower_at<D>(gr, gc)] : 0.0;
+    static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
+    if (dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            if (q * D::NWAVES + wave < D::NTRI && tj[q] < PVT && ti[q] > tj[q]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dbgLi[size_t(16 * ti[q] + (lane >> 4) + 4 * r) * D::NP + 16 * tj[q] + (lane & 15)] = acc[q][r];
+            }
         }
-        __syncthreads();
+        for (int e = tid; e < (D::NP - 16 * PVT) * (D::NP - 16 * PVT); e += D::BLOCK) {  // throttle corner, from LDS
+            const int gr = 16 * PVT + e / (D::NP - 16 * PVT), gc = 16 * PVT + e % (D::NP - 16 * PVT);
+            if (gc <= gr) dbgLi[size_t(gr) * D::NP + gc] = Lb[lower_at<D>(gr, gc)];
+        }
     }
 
     VS_STAMP(4);
@@ -989,15 +1050,18 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
     // they respect their box the sweep simply continues into the joints (active-set iteration 1 of the
     // oracle's rule); otherwise the box QP on the Schur complement runs and the sweep restarts with the
     // throttles prescribed.
+    // The joint columns of the factor are in registers by now (their right-hand side entries were put into sW when
+    // the tiles came back from the panel); the throttle corner is in LDS, and so is everything the box QP touches.
     const bool hold = sIn[VSMPC_IN_HOLD] != 0.0;
-    constexpr int PV = D::NU >> 4;  // first tile that contains a throttle row
-    if (tid < D::NP) {
-        sW[tid] = tid < D::NZ ? -Lb[lower_at<D>(D::NZ, tid)] : 0.0;
-        sZ[tid] = (hold && tid >= D::NZ - 4 && tid < D::NZ) ? sVprev[tid - (D::NZ - 4)] : 0.0;
-    }
+    constexpr int PV = D::PVT;  // first tile that contains a throttle row
+    auto init_corner_rhs = [&]() {
+        if (tid >= 16 * PV && tid < D::NP) sW[tid] = tid < D::NZ ? -Lb[lower_at<D>(D::NZ, tid)] : 0.0;
+    };
+    init_corner_rhs();
+    if (tid < D::NP) sZ[tid] = (hold && tid >= D::NZ - 4 && tid < D::NZ) ? sVprev[tid - (D::NZ - 4)] : 0.0;
     __syncthreads();
 
-    // one tile step of the sweep; `prescribed` = throttles already fixed in sZ
+    // one tile step of the sweep over the corner; `prescribed` = throttles already fixed in sZ
     auto sweep_tile = [&](int p, bool prescribed) {
         if (wave == 0) {
             const int j = lane & 15;  // lane j owns column j of L_pp
@@ -1025,8 +1089,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             if (lane < 16) sZ[gj] = z;
         }
         __syncthreads();
-        if (p > 0) {
-            if (tid < 16 * p) {
+        if (p > PV) {  // corner columns only: the joint columns are updated from registers in P5
+            if (tid >= 16 * PV && tid < 16 * p) {
                 const double* T = Lb + tile_off<D>(p, tid >> 4) + (tid & 15);
                 const double* zp = sZ + 16 * p;
                 double a2 = 0.0;
@@ -1038,8 +1102,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         }
     };
 
-    // the dual box QP and the chain-free first pass need the throttle block to span exactly two tile rows
-    constexpr bool DUALQP = S::FASTSWEEP && D::NT - 2 == PV && D::NV >= 20 && D::NV <= 32;
+    constexpr bool DUALQP = S::DUALQP;
     if constexpr (DUALQP) {
         // The throttle block spans two tile rows.  Last tile row: only its KL = NZ - 16 (NT-1) throttle rows take part
         // (gradient row and padding have z = 0), the hold pins sit here.  First throttle tile row: no pins, and the
@@ -1051,7 +1114,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         const double* L77 = Lb + tile_off<D>(PL, PL);
         if (wave == 0) {
             // wavefront 0 runs both throttle tile rows back to back in registers (cross-lane traffic through
-            // v_readlane only): one workgroup barrier instead of three before the joints' right-hand side is updated
+            // v_readlane only)
             const int j = lane & 15;
             const int gj = 16 * PL + j;
             const double* Tpp = L77 + j;
@@ -1081,25 +1144,6 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
 #pragma unroll
             for (int i = 0; i < 16; ++i) z6 = fma(x6[i], readlane_f64(w6, i), z6);
             if (lane < 16) { sZ[gj] = z; sZ[16 * PV + j] = z6; }
-        }
-        __syncthreads();
-        if (tid < 16 * PV) {
-            const double* T7 = Lb + tile_off<D>(PL, tid >> 4) + (tid & 15);
-            const double* T6 = Lb + tile_off<D>(PV, tid >> 4) + (tid & 15);
-            const double* z7 = sZ + 16 * PL;
-            const double* z6 = sZ + 16 * PV;
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < KL; k += 2) {
-                a0 = fma(T7[k * 17], z7[k], a0);
-                a1 = fma(T7[(k + 1) * 17], z7[k + 1], a1);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-                a0 = fma(T6[k * 17], z6[k], a0);
-                a1 = fma(T6[(k + 1) * 17], z6[k + 1], a1);
-            }
-            sW[tid] -= a0 + a1;
         }
         __syncthreads();
     } else {
@@ -1137,8 +1181,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
         {
             // second tile row of X by all wavefronts:  [X76 | X77] = [-X77 (L76 X66) | L77^-1]
             constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
-            double* sXr = sX + D::NV * NVS;                               // sXr[a * NVS + j] = X[16 + a][j]
-            double* sT = sX;                                              // T = L76 X66, NR2 x 16 (dead before sK is used)
+            double* sXr = sQP + D::NV * NVS;                              // sXr[a * NVS + j] = X[16 + a][j]
+            double* sT = sQP;                                             // T = L76 X66, NR2 x 16 (dead before sK is used)
             const double* X6 = sXinv + PV * D::TS;
             const double* L76 = Lb + tile_off<D>(PV + 1, PV);
             const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
@@ -1187,9 +1231,8 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
             constexpr int NR2 = D::NV - 16;         // throttle rows in the second tile row
             double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
-            double* sK = sX;                        // working copy of P_AA (sX / sF are free until P6)
-            double* sXr = sX + D::NV * NVS;         // rows 16.. of X: sXr[a * NVS + j] = X[16 + a][j]
-            static_assert(D::NV * NVS + NR2 * NVS <= D::NXS + NX * D::N, "work arrays fit sX | sF");
+            double* sK = sQP;                       // working copy of P_AA
+            double* sXr = sQP + D::NV * NVS;        // rows 16.. of X: sXr[a * NVS + j] = X[16 + a][j]
             const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
             const bool valid = lane < D::NV;
             const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
@@ -1205,7 +1248,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             // violations can occur.
             int state = 0;  // 0 free, -1 at lower, +1 at upper (pinned throttles are outside N altogether)
             double v = vu;
-            int best, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
+            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
             {
                 const double tolv = 1e-12 * (1.0 + fabs(v));
                 const bool vlo = inN && (v < lo - tolv);
@@ -1303,7 +1346,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 const int ninf = __popcll(imask);
                 if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
                 bool pick = inf;
-                if (ninf < best) { best = ninf; patience = 3; }
+                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
                 else if (patience > 0) { --patience; }
                 else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
                 if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
@@ -1331,7 +1374,6 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 sum += Lb[lower_at<D>(D::NU + tid, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
             sSvec[tid] = sum;
         }
-        if (tid < D::NP) sW[tid] = tid < D::NZ ? -Lb[lower_at<D>(D::NZ, tid)] : 0.0;  // restart the sweep
         __syncthreads();
 
         if (wave == 0) {
@@ -1353,7 +1395,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
             // backward sweep that just ran (its throttles are in sZ).  Apply its flips here instead of repeating
             // the solve; nothing is at a bound yet, so only primal violations can occur.
             double v = sZ[D::NU + r];
-            int best, patience = 3, status = VSMPC_STATUS_MAX_ITER, iters = 1;
+            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1;
             {
                 const double tolv = 1e-12 * (1.0 + fabs(v));
                 const bool vlo = valid && state == 0 && (v < lo - tolv);
@@ -1425,7 +1467,7 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
                 const int ninf = __popcll(imask);
                 if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
                 bool pick = inf;
-                if (ninf < best) { best = ninf; patience = 3; }
+                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
                 else if (patience > 0) { --patience; }
                 else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
                 if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
@@ -1439,60 +1481,25 @@ __global__ __launch_bounds__(D::BLOCK, D::BLOCK / 256) void solve_kernel(DevCfg 
       }
         __syncthreads();
         VS_STAMP(6);
-        if constexpr (S::FASTSWEEP) {
-            if (tid < D::NU) {
-                const double* Lc = Lb + tile_off<D>(PV, tid >> 4) + (tid & 15);  // rows NU.. of column tid, tile by tile
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < D::NV; c += 2) {
-                    a0 = fma(Lc[((c >> 4) * (tile_off<D>(PV + 1, 0) - tile_off<D>(PV, 0))) + (c & 15) * 17], sZ[D::NU + c], a0);
-                    a1 = fma(Lc[(((c + 1) >> 4) * (tile_off<D>(PV + 1, 0) - tile_off<D>(PV, 0))) + ((c + 1) & 15) * 17],
-                             sZ[D::NU + c + 1], a1);
-                }
-                sW[tid] = -Lb[lower_at<D>(D::NZ, tid)] - (a0 + a1);  // y_U - L21^T v
-            }
+        if constexpr (D::NU % 16 != 0) {
+            // joint rows share the first corner tile row with throttle rows: redo the corner sweep with the throttles
+            // prescribed (its right-hand side starts over from y)
+            init_corner_rhs();
             __syncthreads();
-        } else {
 #pragma unroll 1
-            for (int p = D::NT - 1; p >= 0; --p) sweep_tile(p, true);
+            for (int p = D::NT - 1; p >= PV; --p) sweep_tile(p, true);
         }
     } else {
         VS_STAMP(6);
-        if constexpr (!S::FASTSWEEP) {
-#pragma unroll 1
-            for (int p = PV - 1; p >= 0; --p) sweep_tile(p, false);
-        }
     }
-    if constexpr (S::FASTSWEEP) {
-        // joint tiles: with G_pq = L_pp^-1 L_pq the right-hand sides of the tiles left of p are updated straight from
-        // w_p (no triangular solve on the chain): w_q -= G_pq^T w_p; afterwards every z_p = L_pp^-T w_p at once
-#pragma unroll
-        for (int p = PV - 1; p >= 1; --p) {
-            if (tid < 16 * p) {
-                const double* G = sG + (p * (p - 1) / 2 + (tid >> 4)) * D::TS + (tid & 15);
-                const double* wp = sW + 16 * p;
-                double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; k += 2) {
-                    a0 = fma(G[k * 17], wp[k], a0);
-                    a1 = fma(G[(k + 1) * 17], wp[k + 1], a1);
-                }
-                sW[tid] -= a0 + a1;
-            }
-            __syncthreads();
-        }
-        if (tid < D::NU) {
-            const double* X = sXinv + (tid >> 4) * D::TS + (tid & 15);
-            const double* wp = sW + (tid & ~15);
-            double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                z0 = fma(X[i * 17], wp[i], z0);
-                z1 = fma(X[(i + 1) * 17], wp[i + 1], z1);
-            }
-            sZ[tid] = z0 + z1;
-        }
+    // ---------------------------------------------------------------- P5 joints from the register-resident factor
+    switch (wave) {
+        case 0: backsub_wave<D, TPW, 0>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
+        case 1: backsub_wave<D, TPW, 1>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
+        case 2: backsub_wave<D, TPW, 2>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
+        default: backsub_wave<D, TPW, 3>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
     }
+    __syncthreads();
     if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
     __syncthreads();
 
@@ -1752,22 +1759,30 @@ hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipS
 }
 
 // ------------------------------------------------------------------------------------------------
-// launchers
+// launchers.  The kernels are straight-line template instantiations over Dims<nIter, nIterSmall, controlHorizon>; the
+// table of instantiated horizons is csrc/vsmpc_horizons.def (one X(...) line per horizon, generated by build.py from
+// the list of horizons to support).  Variant ids are 1-based positions in that table.
 // ------------------------------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 64;
+
 template <class D, bool STAMPS>
 static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
-                                 unsigned long long* stamps, double* ws, hipStream_t stream) {
-    if (!D::L_IN_LDS && ws == nullptr) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(Smem<D>::bytes));
+                                 unsigned long long* stamps, hipStream_t stream) {
+    // the dynamic-LDS limit is a per-device function attribute: one process may drive several devices
+    static bool attr_set[MAX_DEVICES] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(Smem<D>::bytes));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((solve_kernel<D, STAMPS>), dim3(batch), dim3(D::BLOCK), Smem<D>::bytes, stream, cfg, d_in, batch,
-                       d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps, ws);
+                       d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
     return hipGetLastError();
 }
 
@@ -1778,66 +1793,74 @@ static hipError_t launch_linearize_t(const DevCfg& cfg, const double* d_in, int 
     return hipGetLastError();
 }
 
-using DimsPaper = Dims<17, 7, 12>;
-using DimsH2x = Dims<34, 14, 24>;  // BASELINE.json configs[4]: 2x horizon at halved fast-rate dt
+struct HorizonEntry {
+    int n_iter, n_iter_small, control_horizon, n_p;
+    size_t lds_bytes;
+    const char* name;
+};
+#define VSMPC_STR2(x) #x
+#define VSMPC_STR(x) VSMPC_STR2(x)
+static const HorizonEntry kHorizons[] = {
+#define X(N, NS, HC) {N, NS, HC, Dims<N, NS, HC>::NP, Smem<Dims<N, NS, HC>>::bytes, "solve_kernel<Dims<" VSMPC_STR(N) "," VSMPC_STR(NS) "," VSMPC_STR(HC) ">>"},
+#include "vsmpc_horizons.def"
+#undef X
+};
+constexpr int kNumHorizons = int(sizeof(kHorizons) / sizeof(kHorizons[0]));
 
 int select_variant(int n_iter, int n_iter_small, int control_horizon) {
-    if (n_iter == 17 && n_iter_small == 7 && control_horizon == 12) return VARIANT_PAPER;
-    if (n_iter == 34 && n_iter_small == 14 && control_horizon == 24) return VARIANT_H2X;
+    for (int i = 0; i < kNumHorizons; ++i)
+        if (kHorizons[i].n_iter == n_iter && kHorizons[i].n_iter_small == n_iter_small &&
+            kHorizons[i].control_horizon == control_horizon)
+            return i + 1;
     return VARIANT_NONE;
 }
 
+int num_variants() { return kNumHorizons; }
+
+void variant_horizon(int variant, int* n_iter, int* n_iter_small, int* control_horizon) {
+    const HorizonEntry& h = kHorizons[variant - 1];
+    *n_iter = h.n_iter;
+    *n_iter_small = h.n_iter_small;
+    *control_horizon = h.control_horizon;
+}
+
 const char* variant_kernel_name(int variant) {
-    switch (variant) {
-        case VARIANT_PAPER: return "solve_kernel<Dims<17,7,12>>";
-        case VARIANT_H2X: return "solve_kernel<Dims<34,14,24>>";
-        default: return "none";
-    }
+    return (variant >= 1 && variant <= kNumHorizons) ? kHorizons[variant - 1].name : "none";
 }
 
 int variant_condensed_dim(int variant) {
-    switch (variant) {
-        case VARIANT_PAPER: return DimsPaper::NP;
-        case VARIANT_H2X: return DimsH2x::NP;
-        default: return 0;
-    }
+    return (variant >= 1 && variant <= kNumHorizons) ? kHorizons[variant - 1].n_p : 0;
 }
 
-size_t variant_workspace_doubles(int variant) {
-    switch (variant) {
-        case VARIANT_PAPER: return DimsPaper::L_WORKSPACE_DOUBLES;
-        case VARIANT_H2X: return DimsH2x::L_WORKSPACE_DOUBLES;
-        default: return 0;
-    }
+size_t variant_lds_bytes(int variant) {
+    return (variant >= 1 && variant <= kNumHorizons) ? kHorizons[variant - 1].lds_bytes : 0;
 }
 
 hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                         int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
-                        double* ws, hipStream_t stream) {
-    switch (variant) {
-        case VARIANT_PAPER:
-            if (stamps != nullptr)
-                return launch_solve_t<DimsPaper, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
-                                                       stamps, ws, stream);
-            return launch_solve_t<DimsPaper, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
-                                                    nullptr, ws, stream);
-        case VARIANT_H2X:
-            if (stamps != nullptr)
-                return launch_solve_t<DimsH2x, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
-                                                     ws, stream);
-            return launch_solve_t<DimsH2x, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, nullptr,
-                                                  ws, stream);
-        default: return hipErrorInvalidValue;
+                        hipStream_t stream) {
+    int id = 0;
+#define X(N, NS, HC)                                                                                                  \
+    if (variant == ++id) {                                                                                            \
+        if (stamps != nullptr)                                                                                        \
+            return launch_solve_t<Dims<N, NS, HC>, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,  \
+                                                         stamps, stream);                                             \
+        return launch_solve_t<Dims<N, NS, HC>, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,     \
+                                                      nullptr, stream);                                               \
     }
+#include "vsmpc_horizons.def"
+#undef X
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                             double* Bt, double* c, hipStream_t stream) {
-    switch (variant) {
-        case VARIANT_PAPER: return launch_linearize_t<DimsPaper>(cfg, d_in, batch, A, Bj, Bt, c, stream);
-        case VARIANT_H2X: return launch_linearize_t<DimsH2x>(cfg, d_in, batch, A, Bj, Bt, c, stream);
-        default: return hipErrorInvalidValue;
-    }
+    int id = 0;
+#define X(N, NS, HC) \
+    if (variant == ++id) return launch_linearize_t<Dims<N, NS, HC>>(cfg, d_in, batch, A, Bj, Bt, c, stream);
+#include "vsmpc_horizons.def"
+#undef X
+    return hipErrorInvalidValue;
 }
 
 }  // namespace vsmpc

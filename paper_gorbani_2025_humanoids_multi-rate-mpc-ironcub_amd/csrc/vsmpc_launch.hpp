@@ -7,16 +7,18 @@
 
 namespace vsmpc {
 
-enum Variant { VARIANT_NONE = 0, VARIANT_PAPER = 1, VARIANT_H2X = 2 };
+enum Variant { VARIANT_NONE = 0 };  // 1.. = position in csrc/vsmpc_horizons.def
 
 int select_variant(int n_iter, int n_iter_small, int control_horizon);
+int num_variants();
+void variant_horizon(int variant, int* n_iter, int* n_iter_small, int* control_horizon);
 const char* variant_kernel_name(int variant);
 int variant_condensed_dim(int variant);
-size_t variant_workspace_doubles(int variant);  // per-instance global workspace of the factor (0 = lives in LDS)
+size_t variant_lds_bytes(int variant);  // dynamic LDS of one workgroup (<= 80 KB: two workgroups share a CU)
 
 hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                         int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
-                        double* ws, hipStream_t stream);
+                        hipStream_t stream);
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                             double* Bt, double* c, hipStream_t stream);
 
