@@ -196,4 +196,51 @@ struct TileTab {
     }
 };
 
+// Number of accumulator slots of wavefront w that are active in SYRK pass m (nodes 2m, 2m+1): the table is sorted by
+// first stage, so the active slots of a wavefront are a prefix.  One scalar load per pass instead of 3 registers per slot.
+template <class D>
+struct NactTab {
+    static constexpr int NPASS = (D::N + 1) / 2;
+    static constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
+    int n[NPASS][D::NWAVES];
+    constexpr NactTab() : n{} {
+        constexpr TileTab<D> tab{};
+        for (int m = 0; m < NPASS; ++m) {
+            const int last = (2 * m + 1 < D::N) ? 2 * m + 1 : 2 * m;
+            for (int w = 0; w < D::NWAVES; ++w) {
+                int c = 0;
+                for (int q = 0; q < TPW; ++q) c += (last >= tab.ts[q * D::NWAVES + w]) ? 1 : 0;
+                n[m][w] = c;
+            }
+        }
+    }
+};
+
+// Tile coordinates of a wavefront's slots, two slots per 32-bit word (ti | tj << 8 per slot): a handful of scalar
+// registers instead of two address registers per slot.
+template <class D>
+struct TilePack {
+    static constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
+    static constexpr int NWORDS = (TPW + 1) / 2;
+    unsigned w[D::NWAVES][NWORDS];
+    constexpr TilePack() : w{} {
+        constexpr TileTab<D> tab{};
+        for (int wv = 0; wv < D::NWAVES; ++wv)
+            for (int q = 0; q < TPW; ++q) {
+                const int t = q * D::NWAVES + wv;
+                w[wv][q >> 1] |= unsigned(tab.ti[t] | (tab.tj[t] << 8)) << (16 * (q & 1));
+            }
+    }
+};
+
+// configuration scalars kept in LDS (copied out of the kernel arguments once; no SGPRs held for them)
+constexpr int CFG_SQ = 0;        // 18 sqrt weights
+constexpr int CFG_WJ = 18;       // 8 joint weights
+constexpr int CFG_WREG = 26;
+constexpr int CFG_WTHR = 27;
+constexpr int CFG_WINIT = 28;
+constexpr int CFG_VMIN = 29;
+constexpr int CFG_VMAX = 30;
+constexpr int CFG_SIZE = 32;
+
 }  // namespace vsmpc

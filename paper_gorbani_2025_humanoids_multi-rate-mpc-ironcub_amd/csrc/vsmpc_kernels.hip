@@ -44,6 +44,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <class D>
 __device__ constexpr TileTab<D> kTileTab{};
+template <class D>
+__device__ constexpr NactTab<D> kNactTab{};
+template <class D>
+__device__ constexpr TilePack<D> kTilePack{};
 
 VS_DEV double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -92,7 +96,8 @@ struct Smem {
     static constexpr int oSvec = oZ + D::NP;
     static constexpr int oV = oSvec + D::NV;
     static constexpr int oDt = oV + D::NV;           // per-stage dt (copied out of the kernel arguments once)
-    static constexpr int oFlags = oDt + MAX_STAGES;  // 4 doubles worth of int flags
+    static constexpr int oCfg = oDt + MAX_STAGES;    // configuration scalars (CFG_* offsets)
+    static constexpr int oFlags = oCfg + CFG_SIZE;   // 4 doubles worth of int flags
     // X_p = L_pp^-1 of the joint diagonal tiles and of the first throttle tile, produced by wavefronts that idle
     // during the panel factorisations of P3
     static constexpr int NXT = D::PVT + 1;
@@ -108,8 +113,7 @@ struct Smem {
     static constexpr int oQP = oSv + D::NV * NVS;    // dual form only: K | rows 16.. of X
     static constexpr int sizeQP = DUALQP ? D::NV * NVS + (D::NV - 16) * NVS : 0;
     static constexpr int oU = oQP + sizeQP;          // per-wavefront partial sums of L^T z, NP each
-    static constexpr int oZw = oU + D::NWAVES * D::NP;  // per-wavefront scratch: d (16) | z (16)
-    static constexpr int oX = oZw + D::NWAVES * 32;  // P6: state trajectory
+    static constexpr int oX = oU + D::NWAVES * D::NP;  // P6: state trajectory
     static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
     static constexpr int endScratch = oF + NX * D::N;
     static_assert(endScratch <= oR + D::RING_TILES * D::TS, "P4..P6 scratch must not reach the corner tiles");
@@ -137,8 +141,8 @@ VS_DEV int lower_at(int gr, int gc) {
 // ------------------------------------------------------------------------------------------------
 // P0: linearisation into LDS (dense, row-major) — also the body of the linearise-only kernel
 // ------------------------------------------------------------------------------------------------
-template <class D, bool ZERO = true>
-VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, double* __restrict__ sA,
+template <class D, bool ZERO = true, bool SYNC = true>
+VS_DEV void p0_linearize(int use_jet, const double* __restrict__ sIn, double* __restrict__ sA,
                          double* __restrict__ sBj, double* __restrict__ sBt, double* __restrict__ sC,
                          double* __restrict__ sVprev, int tid, int nthreads) {
     if constexpr (ZERO) {
@@ -173,7 +177,7 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
         // jets                                                      (systemDynamicsVSMPC.cpp:384-429)
         const int i = tid - 64;
         sVprev[i] = Jet::v_of_throttle_div(sIn[VSMPC_IN_UPREV + i]);
-        if (cfg.use_jet) {
+        if (use_jet) {
             const double T0 = sIn[VSMPC_IN_T0 + i], Td0 = sIn[VSMPC_IN_TD0 + i], up = sIn[VSMPC_IN_UPREV + i];
             const double dhT = Jet::dh_dT(T0, Td0, up), dhTd = Jet::dh_dTd(T0, Td0, up);
             sA[(12 + i) * NX + 16 + i] = 1.0;
@@ -218,7 +222,7 @@ VS_DEV void p0_linearize(const DevCfg& cfg, const double* __restrict__ sIn, doub
         const int e = tid - 136, r = e >> 3, j = e & 7;  // Lambda_ang,B -> Bj[9..11]  (:94-95)
         sBj[(9 + r) * NJ + j] = sIn[VSMPC_IN_LANG + e];
     }
-    __syncthreads();
+    if constexpr (SYNC) __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(DevCfg cfg, const double
     double* sBt = sBj + NX * NJ;
     double* sC = sBt + NX * NTH;
     double* sVprev = sC + 28;
-    p0_linearize<D>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, 256);
+    p0_linearize<D>(cfg.use_jet, sIn, sA, sBj, sBt, sC, sVprev, tid, 256);
     for (int i = tid; i < NX * NX; i += 256) A[size_t(b) * NX * NX + i] = sA[i];
     for (int i = tid; i < NX * NJ; i += 256) Bj[size_t(b) * NX * NJ + i] = sBj[i];
     for (int i = tid; i < NX * NTH; i += 256) Bt[size_t(b) * NX * NTH + i] = sBt[i];
@@ -249,48 +253,106 @@ __global__ __launch_bounds__(256) void linearize_kernel(DevCfg cfg, const double
 // cost terms on the condensed inputs (P2)
 // ------------------------------------------------------------------------------------------------
 template <class D>
-VS_DEV double input_cost_term(const DevCfg& cfg, const double* __restrict__ sIn,
+VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __restrict__ sIn,
                               const double* __restrict__ sVprev, int gr, int gc) {
-    if (gr < D::NU) return (gr == gc) ? cfg.wj[gr & 7] : 0.0;  // (65000+20) I  (costsVSMPC.cpp:375-381,564-571)
+    if (gr < D::NU) return (gr == gc) ? sCfg[CFG_WJ + (gr & 7)] : 0.0;  // (65000+20) I  (costsVSMPC.cpp:375-381,564-571)
     if (gr < D::NZ) {
         if (gc < D::NU) return 0.0;
         const int q1 = gr - D::NU, q2 = gc - D::NU;
         if ((q1 & 3) != (q2 & 3)) return 0.0;
         const int b1 = v_block_of_internal<D>(q1), b2 = v_block_of_internal<D>(q2);
         if (b1 == b2)  // first-difference penalty + v0 anchor  (costsVSMPC.cpp:383-409,472-476)
-            return cfg.w_thr * double((b1 > 0) + (b1 < D::NVB - 1)) + (b1 == 0 ? cfg.w_init : 0.0);
+            return sCfg[CFG_WTHR] * double((b1 > 0) + (b1 < D::NVB - 1)) + (b1 == 0 ? sCfg[CFG_WINIT] : 0.0);
         const int db = b1 - b2;
-        return (db == 1 || db == -1) ? -cfg.w_thr : 0.0;
+        return (db == 1 || db == -1) ? -sCfg[CFG_WTHR] : 0.0;
     }
     if (gr == D::NZ && gc < D::NZ) {  // gradient row
-        if (gc < D::NU) return cfg.w_reg * sIn[VSMPC_IN_QERR + (gc & 7)];      // costsVSMPC.cpp:586-590
+        if (gc < D::NU) return sCfg[CFG_WREG] * sIn[VSMPC_IN_QERR + (gc & 7)];      // costsVSMPC.cpp:586-590
         const int q = gc - D::NU;
-        return v_block_of_internal<D>(q) == 0 ? -cfg.w_init * sVprev[q & 3] : 0.0;  // costsVSMPC.cpp:479-485
+        return v_block_of_internal<D>(q) == 0 ? -sCfg[CFG_WINIT] * sVprev[q & 3] : 0.0;  // costsVSMPC.cpp:479-485
     }
     return 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // SYRK of P1, one accumulator tile (slot) at a time: NKS k-steps of 4 rows as ONE dependent chain on the tile's
-// accumulator (a dependent v_mfma_f64_16x16x4_f64 issues every 64 cycles, like independent ones), operands of the
-// whole chain requested up front.  The caller walks the active slots with one scalar branch per slot; inside a slot
-// the code is branch-free so that the compiler can count the outstanding LDS loads.  (Through v9 a pass was one
-// straight-line stream over all active slots, instantiated per slot count: 630 static matrix-core instructions whose
-// accumulator phis cost a second set of accumulator registers -- unaffordable at two workgroups per CU.)
-// `an`/`bn` carry the first operand pair of the NEXT slot, requested before this slot's chain starts.
+// accumulator (a dependent v_mfma_f64_16x16x4_f64 issues every 64 cycles, like independent ones).
+//   * The active slots of a wavefront are a prefix 0..nact-1; the caller enters a straight-line sequence
+//     slot nact-1, ..., slot 0 through a switch with fall-through.  Every accumulator reaches its own chain unmodified
+//     on every path, so no control-flow join carries a modified accumulator: no copies of the eight accumulator
+//     registers, no second register set, no hazard stalls at joins (through v9 a pass was one stream over all active
+//     slots instantiated per slot count, whose joins cost a second set of accumulator registers -- unaffordable at two
+//     workgroups per CU).
+//   * Operand loads are software-pipelined SYRK_DIST instructions ahead ACROSS slots and pinned with sched_barrier:
+//     the wave's stream blocks at every MFMA issue until the pipe is free (64 cycles), an LDS read returns in ~130, so
+//     a load issued behind instruction e is there for instruction e + 3.  `ha`/`hb` carry the first SYRK_DIST operand
+//     pairs of the slot in and those of the NEXT slot (slot q - 1) out.
 // ------------------------------------------------------------------------------------------------
+constexpr int SYRK_DIST = 3;
+
 template <class D, int NKS>
-VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __restrict__ pb, double a0, double b0,
-                      const double* __restrict__ pan, const double* __restrict__ pbn, double& an, double& bn) {
-    double av[NKS], bv[NKS];
-    av[0] = a0;
-    bv[0] = b0;
+VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __restrict__ pb, double (&ha)[SYRK_DIST],
+                      double (&hb)[SYRK_DIST], const double* __restrict__ pan, const double* __restrict__ pbn) {
+    static_assert(NKS > SYRK_DIST, "pipeline depth");
+    double av[NKS + SYRK_DIST], bv[NKS + SYRK_DIST];
 #pragma unroll
-    for (int ks = 1; ks < NKS; ++ks) { av[ks] = pa[ks * 4 * D::YS]; bv[ks] = pb[ks * 4 * D::YS]; }
-    an = pan[0];
-    bn = pbn[0];
+    for (int ks = 0; ks < SYRK_DIST; ++ks) { av[ks] = ha[ks]; bv[ks] = hb[ks]; }
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < NKS; ++ks) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int n = ks + SYRK_DIST;
+        if (n < NKS) {
+            av[n] = pa[n * 4 * D::YS];
+            bv[n] = pb[n * 4 * D::YS];
+        } else {  // head of the next slot
+            av[n] = pan[(n - NKS) * 4 * D::YS];
+            bv[n] = pbn[(n - NKS) * 4 * D::YS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = av[NKS + ks]; hb[ks] = bv[NKS + ks]; }
+}
+
+// entry into the slot sequence at slot nact - 1 (fall-through switch; see syrk_slot)
+template <class D, int NKS, int TPW, class SA, class SB>
+VS_DEV void syrk_enter(int nact, d4 (&acc)[TPW], double (&ha)[SYRK_DIST], double (&hb)[SYRK_DIST], const SA& slot_a,
+                       const SB& slot_b) {
+    static_assert(TPW <= 30, "extend the switch");
+    switch (nact) {
+        case 30: if constexpr (TPW >= 30) syrk_slot<D, NKS>(acc[29], slot_a(29), slot_b(29), ha, hb, slot_a(28), slot_b(28)); [[fallthrough]];
+        case 29: if constexpr (TPW >= 29) syrk_slot<D, NKS>(acc[28], slot_a(28), slot_b(28), ha, hb, slot_a(27), slot_b(27)); [[fallthrough]];
+        case 28: if constexpr (TPW >= 28) syrk_slot<D, NKS>(acc[27], slot_a(27), slot_b(27), ha, hb, slot_a(26), slot_b(26)); [[fallthrough]];
+        case 27: if constexpr (TPW >= 27) syrk_slot<D, NKS>(acc[26], slot_a(26), slot_b(26), ha, hb, slot_a(25), slot_b(25)); [[fallthrough]];
+        case 26: if constexpr (TPW >= 26) syrk_slot<D, NKS>(acc[25], slot_a(25), slot_b(25), ha, hb, slot_a(24), slot_b(24)); [[fallthrough]];
+        case 25: if constexpr (TPW >= 25) syrk_slot<D, NKS>(acc[24], slot_a(24), slot_b(24), ha, hb, slot_a(23), slot_b(23)); [[fallthrough]];
+        case 24: if constexpr (TPW >= 24) syrk_slot<D, NKS>(acc[23], slot_a(23), slot_b(23), ha, hb, slot_a(22), slot_b(22)); [[fallthrough]];
+        case 23: if constexpr (TPW >= 23) syrk_slot<D, NKS>(acc[22], slot_a(22), slot_b(22), ha, hb, slot_a(21), slot_b(21)); [[fallthrough]];
+        case 22: if constexpr (TPW >= 22) syrk_slot<D, NKS>(acc[21], slot_a(21), slot_b(21), ha, hb, slot_a(20), slot_b(20)); [[fallthrough]];
+        case 21: if constexpr (TPW >= 21) syrk_slot<D, NKS>(acc[20], slot_a(20), slot_b(20), ha, hb, slot_a(19), slot_b(19)); [[fallthrough]];
+        case 20: if constexpr (TPW >= 20) syrk_slot<D, NKS>(acc[19], slot_a(19), slot_b(19), ha, hb, slot_a(18), slot_b(18)); [[fallthrough]];
+        case 19: if constexpr (TPW >= 19) syrk_slot<D, NKS>(acc[18], slot_a(18), slot_b(18), ha, hb, slot_a(17), slot_b(17)); [[fallthrough]];
+        case 18: if constexpr (TPW >= 18) syrk_slot<D, NKS>(acc[17], slot_a(17), slot_b(17), ha, hb, slot_a(16), slot_b(16)); [[fallthrough]];
+        case 17: if constexpr (TPW >= 17) syrk_slot<D, NKS>(acc[16], slot_a(16), slot_b(16), ha, hb, slot_a(15), slot_b(15)); [[fallthrough]];
+        case 16: if constexpr (TPW >= 16) syrk_slot<D, NKS>(acc[15], slot_a(15), slot_b(15), ha, hb, slot_a(14), slot_b(14)); [[fallthrough]];
+        case 15: if constexpr (TPW >= 15) syrk_slot<D, NKS>(acc[14], slot_a(14), slot_b(14), ha, hb, slot_a(13), slot_b(13)); [[fallthrough]];
+        case 14: if constexpr (TPW >= 14) syrk_slot<D, NKS>(acc[13], slot_a(13), slot_b(13), ha, hb, slot_a(12), slot_b(12)); [[fallthrough]];
+        case 13: if constexpr (TPW >= 13) syrk_slot<D, NKS>(acc[12], slot_a(12), slot_b(12), ha, hb, slot_a(11), slot_b(11)); [[fallthrough]];
+        case 12: if constexpr (TPW >= 12) syrk_slot<D, NKS>(acc[11], slot_a(11), slot_b(11), ha, hb, slot_a(10), slot_b(10)); [[fallthrough]];
+        case 11: if constexpr (TPW >= 11) syrk_slot<D, NKS>(acc[10], slot_a(10), slot_b(10), ha, hb, slot_a(9), slot_b(9)); [[fallthrough]];
+        case 10: if constexpr (TPW >= 10) syrk_slot<D, NKS>(acc[9], slot_a(9), slot_b(9), ha, hb, slot_a(8), slot_b(8)); [[fallthrough]];
+        case 9: if constexpr (TPW >= 9) syrk_slot<D, NKS>(acc[8], slot_a(8), slot_b(8), ha, hb, slot_a(7), slot_b(7)); [[fallthrough]];
+        case 8: if constexpr (TPW >= 8) syrk_slot<D, NKS>(acc[7], slot_a(7), slot_b(7), ha, hb, slot_a(6), slot_b(6)); [[fallthrough]];
+        case 7: if constexpr (TPW >= 7) syrk_slot<D, NKS>(acc[6], slot_a(6), slot_b(6), ha, hb, slot_a(5), slot_b(5)); [[fallthrough]];
+        case 6: if constexpr (TPW >= 6) syrk_slot<D, NKS>(acc[5], slot_a(5), slot_b(5), ha, hb, slot_a(4), slot_b(4)); [[fallthrough]];
+        case 5: if constexpr (TPW >= 5) syrk_slot<D, NKS>(acc[4], slot_a(4), slot_b(4), ha, hb, slot_a(3), slot_b(3)); [[fallthrough]];
+        case 4: if constexpr (TPW >= 4) syrk_slot<D, NKS>(acc[3], slot_a(3), slot_b(3), ha, hb, slot_a(2), slot_b(2)); [[fallthrough]];
+        case 3: if constexpr (TPW >= 3) syrk_slot<D, NKS>(acc[2], slot_a(2), slot_b(2), ha, hb, slot_a(1), slot_b(1)); [[fallthrough]];
+        case 2: if constexpr (TPW >= 2) syrk_slot<D, NKS>(acc[1], slot_a(1), slot_b(1), ha, hb, slot_a(0), slot_b(0)); [[fallthrough]];
+        case 1: if constexpr (TPW >= 1) syrk_slot<D, NKS>(acc[0], slot_a(0), slot_b(0), ha, hb, slot_a(0), slot_b(0)); [[fallthrough]];
+        default: break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,7 +494,7 @@ struct WaveLists {
 };
 
 template <class D, int TPW, int W>
-VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
+VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
                           double* __restrict__ sXinv, double* __restrict__ sW, double* __restrict__ dbgL, int lane,
                           int crow, int lrow) {
@@ -448,7 +510,7 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
         if (t < D::NTRI && (tab.ti[t] == tab.tj[t] || tab.ti[t] >= PVT)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[q][r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * tab.ti[t] + (lane >> 4) + 4 * r,
+                acc[q][r] += input_cost_term<D>(sCfg, sIn, sVprev, 16 * tab.ti[t] + (lane >> 4) + 4 * r,
                                                 16 * tab.tj[t] + (lane & 15));
         }
     }
@@ -499,6 +561,21 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
             }
         }
         if (p + 1 < D::NT) {
+            // finished tiles of panel column p come back into the registers that held them (columns of the throttle
+            // corner stay in LDS); the gradient row -> right-hand side y = -L^-1 g of the back-substitution.  Requested
+            // first: the loads complete under the matrix-core work below.
+            if (p < PVT) {
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    const int t = q * D::NWAVES + W;
+                    if (t < D::NTRI && tab.tj[t] == p && tab.ti[t] > p) {
+                        const double* T = sM + tile_off_c<D>(tab.ti[t], p) + crow;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
+                        if (tab.ti[t] == D::NT - 1 && (lane >> 4) == (GL & 3)) sW[16 * p + (lane & 15)] = -acc[q][GL >> 2];
+                    }
+                }
+            }
             // trailing update M_ij -= L_ip L_jp^T for the owned tiles right of the panel; the operands of the next
             // tile are requested before the four matrix-core instructions of the current one
             double la[2][4], lb[2][4];
@@ -531,86 +608,94 @@ VS_DEV void cholesky_wave(const DevCfg& cfg, d4 (&acc)[TPW], double* __restrict_
                     }
                 }
             }
-            // finished tiles of panel column p come back into the registers that held them (columns of the throttle
-            // corner stay in LDS); the gradient row -> right-hand side y = -L^-1 g of the back-substitution
-            if (p < PVT) {
-#pragma unroll
-                for (int q = 0; q < TPW; ++q) {
-                    const int t = q * D::NWAVES + W;
-                    if (t < D::NTRI && tab.tj[t] == p && tab.ti[t] > p) {
-                        const double* T = sM + tile_off_c<D>(tab.ti[t], p) + crow;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
-                        if (tab.ti[t] == D::NT - 1 && (lane >> 4) == (GL & 3)) sW[16 * p + (lane & 15)] = -acc[q][GL >> 2];
-                    }
-                }
-            }
             __syncthreads();
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sum of a per-lane value over the four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48), result in every lane.
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers at VALU latency
+// (a ds_bpermute-based __shfl_xor costs an LDS round trip per step).
+// ------------------------------------------------------------------------------------------------
+VS_DEV double row_sum4(double x) {
+    unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double s = __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
+    lo = __double2loint(s);
+    hi = __double2hiint(s);
+    auto l3 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto h3 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(h3[0], l3[0]) + __hiloint2double(h3[1], l3[1]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // P5 for wavefront W: back-substitution L^T z = w from the REGISTER-resident factor, tile row by tile row from
-// the bottom.  z_r is known (throttle rows: sZ; joint rows: z_r = X_r^T (w_r - u_r), every wavefront forms it
-// redundantly and bit-identically, so no barrier separates it from its use); every owned tile (r, q) then adds
-// L_rq^T z_r to this wavefront's private partial sum u[q] (fixed summation order -> deterministic); one
-// workgroup barrier per tile row.
+// the bottom.  z_r is known (throttle rows: sZ) or formed by every wavefront redundantly and bit-identically on the
+// matrix core: z_r = X_r^T d, d = w_r - sum of the wavefronts' published partial sums, as D = A B with A = X_r^T and
+// every column of B = d -- the result arrives in the accumulator layout, i.e. lane (g, j) holds z[g + 4 i], exactly
+// the operand layout of the owned tiles (lane (g, j) holds L[g + 4 i][j]).  Every owned tile (r, q) then adds
+// L_rq^T z_r to this wavefront's partial sum u_q, kept in registers; the partial sums of column r - 1 are published
+// before the barrier that ends step r (fixed summation order -> deterministic).  One workgroup barrier per tile row.
 // ------------------------------------------------------------------------------------------------
 template <class D, int TPW, int W>
 VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, double* __restrict__ sZ,
-                         const double* __restrict__ sXinv, double* __restrict__ sU, double* __restrict__ sZw, int lane) {
+                         const double* __restrict__ sXinv, double* __restrict__ sU, int lane) {
     constexpr WaveLists<D, TPW, W> wl{};
     constexpr TileTab<D> tab{};
     constexpr int PVT = D::PVT;
     double* myU = sU + W * D::NP;
-    double* myD = sZw + W * 32;
-    double* myZ = myD + 16;
     const int j = lane & 15, g4 = lane >> 4;
-    for (int i = lane; i < 16 * PVT; i += 64) myU[i] = 0.0;  // read by the others only after the first barrier below
+    double up[PVT];
+#pragma unroll
+    for (int q = 0; q < PVT; ++q) up[q] = 0.0;
+    double xop[4];  // A operand of the next joint tile row: X_r[g4 + 4 ks][j], requested one step ahead
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xop[ks] = sXinv[(PVT - 1) * D::TS + (g4 + 4 * ks) * 17 + j];
 #pragma unroll
     for (int r = D::NT - 1; r >= 0; --r) {
-        const double* zsrc = sZ + 16 * r;
+        double zz[4];
         if (r < PVT) {
-            double d = sW[16 * r + j];
-            double usum = sU[16 * r + j];
+            double dop[4];
 #pragma unroll
-            for (int w = 1; w < D::NWAVES; ++w) usum += sU[w * D::NP + 16 * r + j];
-            d -= usum;
-            if (lane < 16) myD[j] = d;
-            const double* X = sXinv + r * D::TS + j;
-            double z0 = 0.0, z1 = 0.0;
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = 16 * r + g4 + 4 * ks;
+                double usum = sU[row];
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {   // z_j = sum_i X[i][j] d_i; myD[i]: uniform address, LDS broadcast
-                z0 = fma(X[i * 17], myD[i], z0);
-                z1 = fma(X[(i + 1) * 17], myD[i + 1], z1);
+                for (int w = 1; w < D::NWAVES; ++w) usum += sU[w * D::NP + row];
+                dop[ks] = sW[row] - usum;
             }
-            const double z = z0 + z1;
-            if (lane < 16) {
-                myZ[j] = z;
-                if (W == 0) sZ[16 * r + j] = z;
+            d4 zt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) zt = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[ks], dop[ks], zt, 0, 0, 0);
+            if (r > 0) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xop[ks] = sXinv[(r - 1) * D::TS + (g4 + 4 * ks) * 17 + j];
             }
-            zsrc = myZ;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zz[i] = zt[i];
+            if (W == 0 && j == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sZ[16 * r + g4 + 4 * i] = zz[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zz[i] = sZ[16 * r + g4 + 4 * i];
         }
         if (r > 0) {
-            if (wl.nrow[r] > 0) {
-                double zz[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) zz[i] = zsrc[g4 + 4 * i];
+            for (int a = 0; a < TPW; ++a) {
+                if (a < wl.nrow[r]) {
+                    const int q = wl.row[r][a];
+                    const int t = q * D::NWAVES + W;
+                    double part = acc[q][0] * zz[0];
 #pragma unroll
-                for (int a = 0; a < TPW; ++a) {
-                    if (a < wl.nrow[r]) {
-                        const int q = wl.row[r][a];
-                        const int t = q * D::NWAVES + W;
-                        double part = acc[q][0] * zz[0];
-#pragma unroll
-                        for (int i = 1; i < 4; ++i) part = fma(acc[q][i], zz[i], part);
-                        part += __shfl_xor(part, 16);
-                        part += __shfl_xor(part, 32);
-                        if (lane < 16) myU[16 * tab.tj[t] + j] += part;
-                    }
+                    for (int i = 1; i < 4; ++i) part = fma(acc[q][i], zz[i], part);
+                    up[tab.tj[t]] += row_sum4(part);
                 }
             }
+            if (r - 1 < PVT && lane < 16) myU[16 * (r - 1) + j] = up[r - 1];
             __syncthreads();
         }
     }
@@ -661,9 +746,10 @@ VS_DEV double small_spd_solve(const double* __restrict__ sP, unsigned long long 
 }
 
 // size dispatch for small_spd_solve (one straight-line instantiation per size)
-constexpr int SMALL_SOLVE_MAX = 12;
+constexpr int SMALL_SOLVE_MAX = 8;
 // block principal pivoting: non-improving block steps tolerated before the least-index fallback (the oracle's value)
 constexpr int AS_PATIENCE = 10;
+constexpr int AS_MAX_ITER = 64;   // active-set iteration cap (status MAX_ITER beyond)
 template <int NVS, int K = SMALL_SOLVE_MAX>
 VS_DEV double small_spd_solve_n(int k, const double* __restrict__ sP, unsigned long long mask, double rhs, int lane, int& bad) {
     if constexpr (K == 1) {
@@ -697,18 +783,43 @@ VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec,
 // ------------------------------------------------------------------------------------------------
 // the solve kernel
 // ------------------------------------------------------------------------------------------------
+// Kernel-argument block as it lies in the kernarg segment.  Everything but `in` and `batch` is needed late (outputs) or
+// rarely (debug dumps, stamps): those are re-read from the kernarg segment where they are used instead of being held in
+// (and spilled from) scalar registers for the whole kernel.  late_args() returns the segment pointer behind an opaque
+// barrier, so the compiler cannot hoist the loads to the top of the kernel.
+struct SolveArgs {
+    DevCfg cfg;
+    const double* in;
+    int batch;
+    int pad_;
+    double* xout;
+    double* fmout;
+    int* status_out;
+    int* iters_out;
+    double* dbgM;
+    double* dbgL;
+    unsigned long long* stamps;
+};
+VS_DEV const SolveArgs* late_args() {
+    const SolveArgs* ka = reinterpret_cast<const SolveArgs*>(
+        (const void*)__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(ka));
+    return ka;
+}
+
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
 // `stamps` (its own buffer, never read by the kernel).  The shipped instantiation has STAMPS = false.
 template <class D, bool STAMPS>
 __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
-                                                         double* __restrict__ xout, double* __restrict__ fmout,
-                                                         int* __restrict__ status_out, int* __restrict__ iters_out,
-                                                         double* __restrict__ dbgM, double* __restrict__ dbgL,
-                                                         unsigned long long* __restrict__ stamps) {
+                                                         double* xout_, double* fmout_, int* status_out_,
+                                                         int* iters_out_, double* dbgM_, double* dbgL_,
+                                                         unsigned long long* stamps_) {
+    // (the trailing parameters are read through late_args(), see SolveArgs)
 #define VS_STAMP(i)                                                                         \
     do {                                                                                    \
         if constexpr (STAMPS) {                                                             \
-            if (threadIdx.x == 0) stamps[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+            unsigned long long* st_ = late_args()->stamps;                                  \
+            if (threadIdx.x == 0) st_[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
         }                                                                                   \
     } while (0)
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -743,32 +854,34 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     double* sX = smem + S::oX;
     double* sF = smem + S::oF;
     double* sDt = smem + S::oDt;
+    double* sCfg = smem + S::oCfg;
     int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);  // [0] numerical failure, [1] status, [2] iters, [3] bound violated
     double* sY = smem + S::oY;
     double* Lb = smem + S::oM;        // tile storage: ring of two panel columns + throttle corner (see Dims)
     double* sXinv = smem + S::oXinv;  // inverses of the joint diagonal tiles and of the first throttle tile
     double* sQP = smem + S::oQP;      // dual box QP work arrays
     double* sU = smem + S::oU;        // register back-substitution: per-wavefront partial sums, scratch
-    double* sZw = smem + S::oZw;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    // Work-item ids are RE-DERIVED at every phase boundary (VS_REFRESH_IDS: lane from v_mbcnt behind an opaque operand,
+    // wave from its scalar register) instead of being carried through the kernel: a value that is live from the first
+    // to the last instruction is the register allocator's favourite spill candidate, and every reload from scratch is a
+    // global-memory round trip on the critical path of a latency-bound workgroup.
+    int tid = threadIdx.x;
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
     const int inst = blockIdx.x;
     if (inst >= batch) return;
+#define VS_REFRESH_IDS()                                                                     \
+    do {                                                                                     \
+        unsigned m_ = ~0u;                                                                   \
+        asm volatile("" : "+s"(m_));                                                         \
+        lane = int(__builtin_amdgcn_mbcnt_hi(m_, __builtin_amdgcn_mbcnt_lo(m_, 0u)));        \
+        tid = (wave << 6) | lane;                                                            \
+    } while (0)
 
-    // tiles of the lower triangle are dealt round-robin to the wavefronts: tile t -> wave t % NWAVES, slot t / NWAVES.
-    // The (wave-uniform) coordinates come from a table in constant memory; requested first so that the scalar loads'
-    // cold-cache latency is spent under P0.
+    // tiles of the lower triangle are dealt round-robin to the wavefronts: tile t -> wave t % NWAVES, slot t / NWAVES
+    // (stage-sorted table in constant memory, padded with never-active dummies)
     constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
-    int ti[TPW], tj[TPW], tstart[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        const int t = q * D::NWAVES + wave;  // entry of the stage-sorted table (padded with never-active dummies)
-        ti[q] = kTileTab<D>.ti[t];
-        tj[q] = kTileTab<D>.tj[t];
-        tstart[q] = kTileTab<D>.ts[t];
-    }
 
     VS_STAMP(0);
     // ---------------------------------------------------------------- P0
@@ -782,18 +895,17 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         if (tid < D::NIN / 2) rec = in2[tid];
         if (tid < 4) sFlags[tid] = 0;
         if (tid < D::N) sDt[tid] = cfg.dt[tid];
+        if (tid >= 64 && tid < 64 + NWROWS) sCfg[CFG_SQ + tid - 64] = cfg.sq[tid - 64];
+        if (tid >= 96 && tid < 96 + NJ) sCfg[CFG_WJ + tid - 96] = cfg.wj[tid - 96];
+        if (tid == 128) {
+            sCfg[CFG_WREG] = cfg.w_reg; sCfg[CFG_WTHR] = cfg.w_thr; sCfg[CFG_WINIT] = cfg.w_init;
+            sCfg[CFG_VMIN] = cfg.vmin; sCfg[CFG_VMAX] = cfg.vmax;
+        }
         for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
         if (tid < D::NIN / 2) sIn2[tid] = rec;
     }
     __syncthreads();
-    p0_linearize<D, false>(cfg, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);
-
-    VS_STAMP(1);
-    if constexpr (STAMPS) stamp_t1 = __builtin_amdgcn_s_memtime();
-    // ---------------------------------------------------------------- P1 condense
-    d4 acc[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    p0_linearize<D, false, false>(cfg.use_jet, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);  // barrier: after P1a below
 
     // P1a: jet sub-system.  The model is a cascade (jets -> momenta -> CoM / RPY -> integrators) and the jets are
     // decoupled from each other, so of the condensed columns only the throttle columns (one jet each) and the affine
@@ -805,7 +917,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     double* sJetT = sXinv;                    // [NJROW][N]; the X tiles are not written before P3
     double* sGA = sJetT + NJROW * D::N;       // [2][N][3]: A_mom T_k of the affine column, per half
     static_assert(D::NV + NTH <= 64 && NJROW * D::N + 6 * D::N <= S::NXT * D::TS, "jet trajectories fit the X region");
-    if (wave == D::NWAVES - 1) {
+    // Runs in the wavefront whose lanes 0..3 linearised the jets (p0_linearize), straight behind that, while the other
+    // wavefronts finish their pieces of P0: LDS operations of one wavefront execute in order, no barrier needed.
+    if (wave == 1) {
         if (lane < D::NV + NTH) {
             const bool affl = lane >= D::NV;
             const int i = affl ? lane - D::NV : (lane & 3);
@@ -828,7 +942,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         }
         for (int k = lane; k < D::N; k += 64) sJetT[ZROW * D::N + k] = 0.0;
     }
-    __syncthreads();
+    __syncthreads();   // ends P0 and the jet trajectories
     for (int e = tid; e < 6 * D::N; e += D::BLOCK) {
         const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3, row = (h ? 9 : 3) + r;
         double g = 0.0;
@@ -837,6 +951,14 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         sGA[e] = g;
     }
     __syncthreads();
+
+    VS_STAMP(1);
+    VS_REFRESH_IDS();
+    if constexpr (STAMPS) stamp_t1 = __builtin_amdgcn_s_memtime();
+    // ---------------------------------------------------------------- P1 condense
+    d4 acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
 
     {
         // P1b: thread (half, c): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy) of the
@@ -862,7 +984,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         };
         double sqx[3], sqh[3], sqe[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { sqx[r] = cfg.sq[yx0 + r]; sqh[r] = cfg.sq[yh0 + r]; sqe[r] = cfg.sq[ye0 + r]; }
+        for (int r = 0; r < 3; ++r) { sqx[r] = sCfg[CFG_SQ + yx0 + r]; sqh[r] = sCfg[CFG_SQ + yh0 + r]; sqe[r] = sCfg[CFG_SQ + ye0 + r]; }
         // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step enters as an
         // immediate offset of ds_read_b64
         const int ylane = (lane >> 4) * D::YS + (lane & 15);
@@ -905,17 +1027,23 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             // four jets enter through sGA)
             jetT[cc] = sJetT + (thr_col ? c - D::NU : ZROW) * D::N;
         }
-        const double* pa[TPW];
-        const double* pb[TPW];
+        // wave-uniform tile coordinates of the slots, packed two slots per scalar register (see TilePack)
+        unsigned tpk[TilePack<D>::NWORDS];
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            pa[q] = sY + ylane + 16 * ti[q];
-            pb[q] = sY + ylane + 16 * tj[q];
-        }
+        for (int k = 0; k < TilePack<D>::NWORDS; ++k) tpk[k] = kTilePack<D>.w[wave][k];
+        const double* ybase = sY + ylane;
+        auto slot_a = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1))) & 0xffu); };
+        auto slot_b = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu); };
 #pragma unroll 1
         for (int m = 0; m < NPASS; ++m) {
             const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
             VS_TIC();
+            // scalar table lookups of this pass's SYRK, requested before the recursion: active slots of this wavefront
+            // (a prefix) and the tile of the first slot to run
+            const int nact = kNactTab<D>.n[m][wave];
+            const int t0 = (nact > 0 ? nact - 1 : 0) * D::NWAVES + wave;
+            const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
+            const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
             load_coeffs();
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -971,21 +1099,36 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             VS_TOC(1);
             // C += Y^T Y over this pass: D = A*B, A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n].
             // Columns that are not active yet are exactly zero, so skipping a tile is only an optimisation.
-            const int last_stage = 2 * m + nnodes - 1;
-            int nact = 0;  // scalar: the table is sorted by first stage, so the active slots are a prefix
+            if constexpr (TPW <= 12) {
+                if (nact > 0) {
+                    // fall-through switch over the slots (see syrk_slot); head operands of the first slot to run
+                    double ha[SYRK_DIST], hb[SYRK_DIST];
 #pragma unroll
-            for (int q = 0; q < TPW; ++q) nact += (last_stage >= tstart[q]) ? 1 : 0;
-            {
-                double a0 = pa[0][0], b0 = pb[0][0], an = 0.0, bn = 0.0;
+                    for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = pa0[ks * 4 * D::YS]; hb[ks] = pb0[ks * 4 * D::YS]; }
+                    if (nnodes == 2) syrk_enter<D, 9, TPW>(nact, acc, ha, hb, slot_a, slot_b);
+                    else syrk_enter<D, 5, TPW>(nact, acc, ha, hb, slot_a, slot_b);
+                }
+            } else {
+                // long horizons (30 slots, one workgroup per CU, 512 registers): one scalar branch per slot in ascending
+                // order; the joins cost accumulator copies, which this register budget affords
+                double ha[SYRK_DIST], hb[SYRK_DIST];
 #pragma unroll
-                for (int q = 0; q < TPW; ++q) {
-                    if (q < nact) {  // scalar branch per slot
-                        const double* pan = pa[q + 1 < TPW ? q + 1 : q];
-                        const double* pbn = pb[q + 1 < TPW ? q + 1 : q];
-                        if (nnodes == 2) syrk_slot<D, 9>(acc[q], pa[q], pb[q], a0, b0, pan, pbn, an, bn);
-                        else syrk_slot<D, 5>(acc[q], pa[q], pb[q], a0, b0, pan, pbn, an, bn);
-                        a0 = an;
-                        b0 = bn;
+                for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = slot_a(0)[ks * 4 * D::YS]; hb[ks] = slot_b(0)[ks * 4 * D::YS]; }
+                if (nnodes == 2) {
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) {
+                        if (q < nact) {
+                            const int qn = q + 1 < TPW ? q + 1 : q;
+                            syrk_slot<D, 9>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) {
+                        if (q < nact) {
+                            const int qn = q + 1 < TPW ? q + 1 : q;
+                            syrk_slot<D, 5>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+                        }
                     }
                 }
             }
@@ -995,46 +1138,52 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         VS_TIC();
     }
     VS_STAMP(2);
+    VS_REFRESH_IDS();
 
     // ---------------------------------------------------------------- P2 + P3 (wave-specialised, see cholesky_wave)
     constexpr int PVT = D::PVT;  // first tile row that contains a throttle row
     const int crow = (lane >> 4) * 17 + (lane & 15);  // C/D fragment: row (lane>>4)+4r, column lane&15
     const int lrow = (lane & 15) * 17 + (lane >> 4);  // A/B fragment: row lane&15, k = lane>>4
+    double* dbgM = late_args()->dbgM;
+    double* dbgL = late_args()->dbgL;
     double* dbgLi = dbgL != nullptr ? dbgL + size_t(inst) * D::NP * D::NP : nullptr;
     if (dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             if (q * D::NWAVES + wave < D::NTRI) {
+                const int ti_q = kTileTab<D>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D>.tj[q * D::NWAVES + wave];
                 d4 tmp = acc[q];
-                if (ti[q] == tj[q] || ti[q] >= PVT) {
+                if (ti_q == tj_q || ti_q >= PVT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        tmp[r] += input_cost_term<D>(cfg, sIn, sVprev, 16 * ti[q] + (lane >> 4) + 4 * r,
-                                                     16 * tj[q] + (lane & 15));
+                        tmp[r] += input_cost_term<D>(sCfg, sIn, sVprev, 16 * ti_q + (lane >> 4) + 4 * r,
+                                                     16 * tj_q + (lane & 15));
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int gr = 16 * ti[q] + (lane >> 4) + 4 * r, gc = 16 * tj[q] + (lane & 15);
+                    const int gr = 16 * ti_q + (lane >> 4) + 4 * r, gc = 16 * tj_q + (lane & 15);
                     if (gc <= gr) dbgM[size_t(inst) * D::NP * D::NP + size_t(gr) * D::NP + gc] = tmp[r];
                 }
             }
         }
     }
     VS_STAMP(3);
+    VS_REFRESH_IDS();
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        case 1: cholesky_wave<D, TPW, 1>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        case 2: cholesky_wave<D, TPW, 2>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        default: cholesky_wave<D, TPW, 3>(cfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 0: cholesky_wave<D, TPW, 0>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 1: cholesky_wave<D, TPW, 1>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 2: cholesky_wave<D, TPW, 2>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        default: cholesky_wave<D, TPW, 3>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
     }
     static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
     if (dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            if (q * D::NWAVES + wave < D::NTRI && tj[q] < PVT && ti[q] > tj[q]) {
+            const int ti_q = kTileTab<D>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D>.tj[q * D::NWAVES + wave];
+            if (q * D::NWAVES + wave < D::NTRI && tj_q < PVT && ti_q > tj_q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    dbgLi[size_t(16 * ti[q] + (lane >> 4) + 4 * r) * D::NP + 16 * tj[q] + (lane & 15)] = acc[q][r];
+                    dbgLi[size_t(16 * ti_q + (lane >> 4) + 4 * r) * D::NP + 16 * tj_q + (lane & 15)] = acc[q][r];
             }
         }
         for (int e = tid; e < (D::NP - 16 * PVT) * (D::NP - 16 * PVT); e += D::BLOCK) {  // throttle corner, from LDS
@@ -1044,6 +1193,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
 
     VS_STAMP(4);
+    VS_REFRESH_IDS();
     // ---------------------------------------------------------------- P4/P5 back-substitution L^T z = y
     // Row NZ of the factor holds L^-1 g, so y = -row.  The throttles sit at the end of the order, hence the
     // first tiles of the backward sweep yield the throttles of the QP with only the hold pin enforced.  If
@@ -1155,13 +1305,14 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         const double v = sZ[D::NU + (valid ? lane : 0)];
         const bool fixed = hold && lane >= D::NV - 4;
         const double tolv = 1e-12 * (1.0 + fabs(v));
-        const bool viol = valid && !fixed && (v < cfg.vmin - tolv || v > cfg.vmax + tolv);
+        const bool viol = valid && !fixed && (v < sCfg[CFG_VMIN] - tolv || v > sCfg[CFG_VMAX] + tolv);
         const unsigned long long vm = __ballot(viol);
         if (lane == 0) { sFlags[3] = __popcll(vm); sFlags[1] = VSMPC_STATUS_SOLVED; sFlags[2] = 1; }
     }
     __syncthreads();
     const bool need_qp = sFlags[3] != 0;
     VS_STAMP(5);
+    VS_REFRESH_IDS();
 
     // few saturated throttles (the usual case): dual form, cost grows with the number of active bounds;
     // many: primal form on the Schur complement, cost grows with the number of free throttles
@@ -1238,8 +1389,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
             const int n = hold ? D::NV - 4 : D::NV;
             const bool inN = valid && r < n;
-            const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
-            const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
+            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
+            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
             const double* X6 = sXinv + PV * D::TS;  // X[i][j], i, j < 16, at i*17 + j; rows 16.. are in sXr (sweep_tile)
             const double gtol = 1e-10 * (1.0 + sSvec[0]);   // sSvec[0] = max |s| (see above)
             const double vu = sZ[D::NU + r];
@@ -1264,7 +1415,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 xc[j] = (j < 16 ? r < 16 : j < n) ? t : 0.0;
             }
             unsigned long long have = 0ull;
-            for (int it = 1; it < cfg.max_as_iter; ++it) {
+            for (int it = 1; it < AS_MAX_ITER; ++it) {
                 iters = it + 1;
                 const bool isA = inN && state != 0;
                 const unsigned long long Amask = __ballot(isA);
@@ -1384,8 +1535,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             for (int c = 0; c < D::NV; ++c) row[c] = sSv[r * (D::NV + 1) + c];
             const double svr = sSvec[r];
             const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
-            const double lo = fixed ? sVprev[r & 3] : cfg.vmin;    // constraintsVSMPC.cpp:351-364
-            const double hi = fixed ? sVprev[r & 3] : cfg.vmax;
+            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
+            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
             int state = fixed ? -1 : 0;  // 0 free, -1 at lower, +1 at upper
             double gmax = fabs(svr);
 #pragma unroll
@@ -1403,7 +1554,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 best = __popcll(__ballot(vlo || vhi));
                 if (vlo || vhi) state = vlo ? -1 : 1;
             }
-            for (int it = 1; it < cfg.max_as_iter; ++it) {
+            for (int it = 1; it < AS_MAX_ITER; ++it) {
                 iters = it + 1;
                 const bool isF = valid && state == 0;
                 const unsigned long long Fmask = __ballot(isF);
@@ -1481,6 +1632,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
       }
         __syncthreads();
         VS_STAMP(6);
+        VS_REFRESH_IDS();
         if constexpr (D::NU % 16 != 0) {
             // joint rows share the first corner tile row with throttle rows: redo the corner sweep with the throttles
             // prescribed (its right-hand side starts over from y)
@@ -1494,16 +1646,17 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     // ---------------------------------------------------------------- P5 joints from the register-resident factor
     switch (wave) {
-        case 0: backsub_wave<D, TPW, 0>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
-        case 1: backsub_wave<D, TPW, 1>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
-        case 2: backsub_wave<D, TPW, 2>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
-        default: backsub_wave<D, TPW, 3>(acc, sW, sZ, sXinv, sU, sZw, lane); break;
+        case 0: backsub_wave<D, TPW, 0>(acc, sW, sZ, sXinv, sU, lane); break;
+        case 1: backsub_wave<D, TPW, 1>(acc, sW, sZ, sXinv, sU, lane); break;
+        case 2: backsub_wave<D, TPW, 2>(acc, sW, sZ, sXinv, sU, lane); break;
+        default: backsub_wave<D, TPW, 3>(acc, sW, sZ, sXinv, sU, lane); break;
     }
     __syncthreads();
     if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
     __syncthreads();
 
     VS_STAMP(7);
+    VS_REFRESH_IDS();
     // ---------------------------------------------------------------- P6 forward simulation + outputs
     // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c
     for (int e = tid; e < NX * D::N; e += D::BLOCK) {
@@ -1634,7 +1787,13 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     __syncthreads();
     VS_STAMP(8);
+    VS_REFRESH_IDS();
 
+    const SolveArgs* ka = late_args();
+    double* xout = ka->xout;
+    double* fmout = ka->fmout;
+    int* status_out = ka->status_out;
+    int* iters_out = ka->iters_out;
     if (xout != nullptr) {
         double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
         for (int i = tid; i < D::NXS / 2; i += D::BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
@@ -1662,13 +1821,15 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     VS_STAMP(9);
     if constexpr (STAMPS) {
+        unsigned long long* st_ = late_args()->stamps;
         if (threadIdx.x == 0) {
             t_acc[5] = __builtin_amdgcn_s_memrealtime() - rt0;
             t_acc[4] = rt0;  // absolute start (global 100 MHz counter): start skew across the workgroups of a launch
-            for (int i = 0; i < 6; ++i) stamps[size_t(blockIdx.x) * 16 + 10 + i] = t_acc[i];
+            for (int i = 0; i < 6; ++i) st_[size_t(blockIdx.x) * 16 + 10 + i] = t_acc[i];
         }
     }
 #undef VS_STAMP
+#undef VS_REFRESH_IDS
 #undef VS_TIC
 #undef VS_TOC
 }
