@@ -59,6 +59,8 @@ struct vsmpc_rollout {
     double* d_talpha;
     double* d_log;
     int log_ticks;
+    double* d_tstate;         // per-instance tick state: reference window FIFO, RPY unwrap (see vsmpc_rollout.hip)
+    int valid;                // 0 after a run failed half-way: the device counters are ahead, reset() before the next run
     double* d_rec;            // record of the next tick ([batch][n_in]): written by reset and by every tick's advance
     RolloutCtl* d_ctl;        // per-run control block read by advance_kernel (log destination, tick base)
     int ticks_done;           // ticks since the last reset (the same for every instance)
@@ -493,6 +495,13 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
     r->rd.n_alpha = n_alpha;
     r->rd.period_mpc = h->cfg.period_mpc;
     r->rd.alpha_dt = alpha_dt;
+    r->rd.n_ts = 12 * r->rd.n_ref + 8;
+    {   // TrajectoryManager::configure(.., 1 / periodMPC): des_fps truncated to int (systemDynamicsVSMPC.cpp:272), integer
+        // up-sampling factor against the track's own rate
+        const int des_fps = int(1.0 / h->cfg.period_mpc + 1e-9), fps = int(std::lround(1.0 / alpha_dt));
+        if (fps <= 0 || des_fps < fps || des_fps % fps != 0) { delete r; return VSMPC_ERR_INVALID_ARG; }
+        r->rd.alpha_up = des_fps / fps;
+    }
     r->substeps = std::min(16, std::max(1, int(std::lround(h->cfg.period_mpc / 1e-3))));  // 1 kHz plant, as the MuJoCo harness
     const size_t B = size_t(batch);
     hipError_t e = hipMalloc(&r->d_state, B * VSMPC_PLANT_STATE * sizeof(double));
@@ -506,6 +515,8 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
     if (e == hipSuccess) e = hipMemcpy(r->d_talpha, traj_alpha, size_t(n_alpha) * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(r->d_tick, 0, B * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&r->d_ctl, sizeof(RolloutCtl));
+    if (e == hipSuccess) e = hipMalloc(&r->d_tstate, B * r->rd.n_ts * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(r->d_tstate, 0, B * r->rd.n_ts * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&r->d_rec, B * h->n_in * sizeof(double));
     if (e == hipSuccess) e = hipMemset(r->d_rec, 0, B * h->n_in * sizeof(double));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking);
@@ -529,6 +540,7 @@ void vsmpc_rollout_destroy(vsmpc_rollout* r) {
     if (r->d_log) (void)hipFree(r->d_log);
     if (r->d_ctl) (void)hipFree(r->d_ctl);
     if (r->d_rec) (void)hipFree(r->d_rec);
+    if (r->d_tstate) (void)hipFree(r->d_tstate);
     if (r->gexec) (void)hipGraphExecDestroy(r->gexec);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
@@ -543,9 +555,11 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
     HIP_TRY(hipMemset(r->d_tick, 0, B * sizeof(int)));
     r->ticks_done = 0;
     // record of tick 0; from here on every tick's advance kernel leaves the record of the following tick
-    HIP_TRY(launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha, r->d_rec,
-                          nullptr));
+    r->valid = 0;
+    HIP_TRY(launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha,
+                          r->d_tstate, r->d_rec, nullptr));
     HIP_TRY(hipDeviceSynchronize());
+    r->valid = 1;
     return VSMPC_OK;
 }
 
@@ -563,7 +577,7 @@ hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
                                 nullptr, nullptr, s);
     if (e == hipSuccess)
         e = launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
-                           r->d_talpha, r->d_ctl, r->substeps, r->d_tpos, r->d_tvel, r->d_rec, s);
+                           r->d_talpha, r->d_ctl, r->substeps, r->d_tpos, r->d_tvel, r->d_tstate, r->d_rec, s);
     return e;
 }
 
@@ -590,6 +604,7 @@ extern "C" {
 
 int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
     if (r == nullptr || ticks < 0) return VSMPC_ERR_INVALID_ARG;
+    if (!r->valid) return VSMPC_ERR_INVALID_ARG;   // never reset, or a previous run failed half-way: reset() first
     if (ticks == 0) return VSMPC_OK;
     vsmpc_handle* h = r->h;
     HIP_TRY(hipSetDevice(h->device));
@@ -603,9 +618,10 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
         if (e != hipSuccess) return e == hipErrorOutOfMemory ? VSMPC_ERR_ALLOC : hip_fail(e, "vsmpc_rollout_run");
         r->log_ticks = ticks;
     }
-    const RolloutCtl ctl = {log ? r->d_log : nullptr, r->ticks_done, 0};
+    const RolloutCtl ctl = {log ? r->d_log : nullptr, r->ticks_done, log ? ticks : 0};
     HIP_TRY(hipMemcpyAsync(r->d_ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));  // `ctl` lives on this stack frame
+    r->valid = 0;                       // until the whole run has completed: a failure below leaves the counters ahead
     int t = 0;
     if (ticks >= GRAPH_TICKS && r->graph_state == 0) build_tick_graph(r, s);
     if (r->graph_state == 1)
@@ -614,6 +630,7 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
     if (log) HIP_TRY(hipMemcpyAsync(log, r->d_log, size_t(ticks) * row * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     r->ticks_done += ticks;
+    r->valid = 1;
     return VSMPC_OK;
 }
 

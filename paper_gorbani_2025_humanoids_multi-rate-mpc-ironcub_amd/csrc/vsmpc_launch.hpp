@@ -27,18 +27,21 @@ hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipS
 // closed-loop rollout (vsmpc_rollout.hip)
 struct RolloutDev {
     int n_in, n_ref, ratio, n_traj, n_alpha;
+    int n_ts;         // doubles of per-instance tick state (reference window, RPY unwrap: see vsmpc_rollout.hip)
+    int alpha_up;     // up-sampling factor of the alpha-gravity track (TrajectoryManager.cpp:23-39)
     double period_mpc, alpha_dt;
 };
 struct RolloutCtl {   // device-resident per-run control block of the rollout
     double* log;      // [ticks of this run][batch][VSMPC_ROLLOUT_LOG] or nullptr
     int tick_base;    // tick counter at the start of the run
-    int pad;
+    int log_rows;     // rows the log buffer holds
 };
 hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,
-                         const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* rec,
-                         hipStream_t stream);
+                         const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* tstate,
+                         double* rec, hipStream_t stream);
 hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
                           const int* status, const int* iters, const double* traj_alpha, const RolloutCtl* ctl, int substeps,
-                          const double* traj_pos, const double* traj_vel, double* rec_next, hipStream_t stream);
+                          const double* traj_pos, const double* traj_vel, double* tstate, double* rec_next,
+                          hipStream_t stream);
 
 }  // namespace vsmpc

@@ -1,12 +1,23 @@
 // Closed-loop batched rollout: the reference's hidden per-tick "advance" on the device.
 //
 //   record_kernel   builds the per-tick input record of every instance from its plant state, i.e. what
-//                   IMPCProblem::update pulls out of Robot/QPInput plus the tick state machine:
-//                     measured state X0                      constraintsVSMPC.cpp:206-230
-//                     20-tick throttle hold                  constraintsVSMPC.cpp:335,351-372
-//                     reference window (10 Hz samples)       costsVSMPC.cpp:103-113,124-165
-//                     alpha-gravity cursor (200 Hz, linear)  systemDynamicsVSMPC.cpp:308-311, TrajectoryManager.cpp:23-39
-//                     joint posture error                    costsVSMPC.cpp:574-589
+//                   IMPCProblem::update pulls out of Robot/QPInput plus the tick state machine, with the reference's own
+//                   call-count semantics (k = number of update() calls before this one; configure() made call 0 of every
+//                   plugin, IMPCProblem.cpp:94-96):
+//                     measured state X0, RPY unwrapped with      constraintsVSMPC.cpp:206-247
+//                       per-instance turn counters
+//                     20-tick throttle hold: v0 free on ticks    constraintsVSMPC.cpp:335,351-372
+//                       k % 20 == 19
+//                     reference window = FIFO of 11 columns,     costsVSMPC.cpp:103-113,121-165
+//                       initially all trajectory sample 0; a
+//                       new sample enters the LAST column in
+//                       configure and on ticks k % 20 == 19 (the
+//                       throttle-release tick); its h_lin entry
+//                       R^T m v is frozen with the R of the push
+//                     alpha-gravity cursor: tick k uses sample   systemDynamicsVSMPC.cpp:308-311,
+//                       k + 1 of the x20 linearly up-sampled       TrajectoryManager.cpp:23-39,142-153
+//                       track (configure consumed sample 0)
+//                     joint posture error                        costsVSMPC.cpp:574-589
 //   solve_kernel    (vsmpc_kernels.hip) the MPC solve
 //   advance_kernel  consumes the first move only if the status is Solved (variableSamplingMPC.cpp:91-108):
 //                   q += dq, throttle / thrust references latched; then integrates a centroidal + jet plant over one
@@ -70,13 +81,43 @@ VS_DEV void stage_in(const double* __restrict__ g, double* __restrict__ l, int l
     }
 }
 
-// Record of tick `tk` from the plant state `s` and parameters `p` (both in LDS), assembled into `r` (LDS) by the 64
-// lanes of the workgroup.  Ends with a barrier: `r` is complete on return.
+// Per-instance tick state that survives between ticks, VSMPC tick-state record in HBM:
+//   [0, 12 n_ref)   reference window, column-major: col * 12 + (p 0:3 | h_lin 3:6 | rpy 6:9 | h_ang 9:12)
+//   + 0..2          m_rpyOld (last measured, wrapped RPY)      constraintsVSMPC.cpp:246
+//   + 3..5          m_nTurns                                    constraintsVSMPC.cpp:236-243
+VS_HD constexpr int tick_state_doubles(int n_ref) { return 12 * n_ref + 8; }
+
+VS_DEV double wrap_pi(double a) {  // what Rotation::asRPY() returns for an angle the plant integrates continuously
+    const double two_pi = 6.283185307179586476925286766559;
+    return a - two_pi * rint(a / two_pi);
+}
+
+// TrajectoryManager semantics for alpha-gravity: linear up-sampling by `up` (TrajectoryManager.cpp:23-39: the last
+// original sample is dropped), cursor advanced once per dynamics evaluation and clamped at the last up-sampled sample
+// (:142-153); configure consumed sample 0, so tick k reads sample k + 1.
+VS_DEV double alpha_of_tick(const double* __restrict__ tr, int n, int up, int tk) {
+    const int last = up * (n - 1) - 1;
+    int idx = tk + 1;
+    idx = idx < last ? idx : last;
+    idx = idx > 0 ? idx : 0;
+    const int i = idx / up, j = idx - up * i;
+    const double v0 = tr[i], v1 = tr[i + 1 < n ? i + 1 : n - 1];
+    return v0 + (v1 - v0) * (double(j) / double(up));
+}
+
+// Record of tick `tk` from the plant state `s`, the parameters `p` and the tick state `ts` (all in LDS), assembled into
+// `r` (LDS) by the 64 lanes of the workgroup; `ts` is advanced to "after update() number tk".  `first` builds the tick
+// state itself: what configure() leaves behind, fast-forwarded to tick `tk` for loops that start mid-trajectory (window
+// columns frozen with the current R, as if the attitude had been constant before).  Ends with a barrier.
 VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, const double* __restrict__ p, int tk,
                             const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
                             const double* __restrict__ traj_alpha, double* __restrict__ R, double* __restrict__ om,
-                            double* __restrict__ r, int lane) {
+                            double* __restrict__ ts, double* __restrict__ r, int lane, bool first) {
     const double m = p[VSMPC_PP_MASS];
+    const int nref = rd.n_ref, nwin = 12 * rd.n_ref;
+    double* rpy_old = ts + nwin;
+    double* n_turns = ts + nwin + 3;
+    const double two_pi = 6.283185307179586476925286766559;
     if (lane == 0) {
         rot_from_rpy(s + VSMPC_PS_RPY, R);
     } else if (lane == 1) {
@@ -84,27 +125,61 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
         inv3(p + VSMPC_PP_INERTIA_B, IBi);
         for (int i = 0; i < 3; ++i)
             om[i] = IBi[3 * i] * s[VSMPC_PS_HANG] + IBi[3 * i + 1] * s[VSMPC_PS_HANG + 1] + IBi[3 * i + 2] * s[VSMPC_PS_HANG + 2];
+    } else if (lane >= 2 && lane < 5) {
+        // ConstraintInitialState::unwrapRPY (constraintsVSMPC.cpp:232-247) on the wrapped measurement
+        const int i = lane - 2;
+        const double meas = wrap_pi(s[VSMPC_PS_RPY + i]);
+        if (first) {
+            n_turns[i] = rint((s[VSMPC_PS_RPY + i] - meas) / two_pi);   // m_rpyOld = initial RPY, turns as flown so far
+        } else {
+            const double d = meas - rpy_old[i];
+            if (d > 3.14159265358979323846) n_turns[i] -= 1.0;
+            else if (d < -3.14159265358979323846) n_turns[i] += 1.0;
+        }
+        rpy_old[i] = meas;
     }
     __syncthreads();
-    // reference window: one column per large step, sample index advances every `ratio` ticks (costsVSMPC.cpp:124-165)
-    const int idx0 = tk / rd.ratio;
-    for (int e = lane; e < 12 * rd.n_ref; e += RO_BLOCK) {
-        const int j = e / 12, i = e - 12 * j;
-        int idx = idx0 + j;
+    // window column from trajectory sample `idx` with the CURRENT attitude and mass (costsVSMPC.cpp:103-113,127-146)
+    auto column_entry = [&](int idx, int i) -> double {
         idx = idx < rd.n_traj ? idx : rd.n_traj - 1;
-        double v;
-        if (i < 3) {
-            v = p[VSMPC_PP_PINIT + i] + traj_pos[3 * idx + i];      // m_initialCoMPos + positionCoM (costsVSMPC.cpp:105-106)
-        } else if (i < 6) {                                          // R^T m v_ref (:107-109)
+        if (i < 3) return p[VSMPC_PP_PINIT + i] + traj_pos[3 * idx + i];   // m_initialCoMPos + positionCoM
+        if (i < 6) {                                                        // R^T m v_ref
             const int c = i - 3;
-            v = R[c] * (m * traj_vel[3 * idx]) + R[3 + c] * (m * traj_vel[3 * idx + 1]) + R[6 + c] * (m * traj_vel[3 * idx + 2]);
-        } else if (i < 9) {
-            v = p[VSMPC_PP_RPYINIT + i - 6];                         // m_initialRPY + RPY trajectory (all zero)
-        } else {
-            v = 0.0;
+            return R[c] * (m * traj_vel[3 * idx]) + R[3 + c] * (m * traj_vel[3 * idx + 1]) + R[6 + c] * (m * traj_vel[3 * idx + 2]);
         }
-        r[VSMPC_IN_XREF + e] = v;
+        if (i < 9) return p[VSMPC_PP_RPYINIT + i - 6];                      // m_initialRPY + RPY trajectory (all zero, A.6)
+        return 0.0;                                                         // I_G W rpy_dot_ref, RPYDot trajectory all zero
+    };
+    if (first) {
+        // shifts made before update() number tk: the one of configure + one per earlier tick with k % ratio == ratio - 1;
+        // shift number s pushed trajectory sample min(s, n_traj - 1), the initial fill is sample 0
+        const int ns0 = 1 + tk / rd.ratio;
+        for (int e = lane; e < nwin; e += RO_BLOCK) {
+            const int j = e / 12, i = e - 12 * j;
+            const int sj = ns0 - (nref - 1 - j);
+            ts[e] = column_entry(sj > 0 ? sj : 0, i);
+        }
+        __syncthreads();
     }
+    if (tk % rd.ratio == rd.ratio - 1) {   // ReferenceTrackingCost::computeHessianAndGradient, m_counter == ratio - 1
+        const int ns = 1 + (tk + 1) / rd.ratio;
+        constexpr int KMAX = (12 * MAX_STAGES + RO_BLOCK - 1) / RO_BLOCK;
+        double keep[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + k * RO_BLOCK;
+            const int j = e / 12, i = e - 12 * j;
+            keep[k] = e < nwin ? (j + 1 < nref ? ts[e + 12] : column_entry(ns, i)) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int e = lane + k * RO_BLOCK;
+            if (e < nwin) ts[e] = keep[k];
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < nwin; e += RO_BLOCK) r[VSMPC_IN_XREF + e] = ts[e];
     // A_mom(q) = A_mom0 + sum_j DJ[j] (q_j - q_ref0_j); Lambda column j = DJ[j] T at the measured thrust
     // (the reference recomputes both from the kinematics each tick, systemDynamicsVSMPC.cpp:159-206,304,321-350)
     if (lane < 24) {
@@ -126,8 +201,8 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
             for (int c = 0; c < 3; ++c) acc += R[3 * i + a] * p[VSMPC_PP_INERTIA_B + 3 * a + c] * R[3 * j + c];
         r[VSMPC_IN_INERTIA + 3 * i + j] = acc;
     }
-    // X0 (constraintsVSMPC.cpp:206-230); |rpy| stays below pi in these rollouts, so unwrapped RPY == RPY
-    if (lane < 20) r[VSMPC_IN_X0 + lane] = s[lane];
+    // X0 (constraintsVSMPC.cpp:206-230): RPY enters unwrapped
+    if (lane < 20) r[VSMPC_IN_X0 + lane] = (lane >= 6 && lane < 9) ? rpy_old[lane - 6] + two_pi * n_turns[lane - 6] : s[lane];
     if (lane >= 20 && lane < 29) r[VSMPC_IN_WRB + lane - 20] = R[lane - 20];
     if (lane >= 32 && lane < 36) {
         const int i = lane - 32;
@@ -141,19 +216,19 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
     if (lane >= 44 && lane < 47) {
         const int i = lane - 44;
         r[VSMPC_IN_OMEGA + i] = om[i];
-        r[VSMPC_IN_RPY + i] = s[VSMPC_PS_RPY + i];
+        r[VSMPC_IN_RPY + i] = rpy_old[i];                // Rotation::asRPY() of the measurement (systemDynamicsVSMPC.cpp:132)
         r[VSMPC_IN_RPYINIT + i] = p[VSMPC_PP_RPYINIT + i];
         r[VSMPC_IN_GRAV + i] = i == 2 ? -9.81 : 0.0;
     }
     if (lane == 47) {
         r[VSMPC_IN_MASS] = m;
-        r[VSMPC_IN_ALPHA] = interp_clamped(traj_alpha, rd.n_alpha, double(tk) * rd.period_mpc / rd.alpha_dt);
+        r[VSMPC_IN_ALPHA] = alpha_of_tick(traj_alpha, rd.n_alpha, rd.alpha_up, tk);
         r[VSMPC_IN_HOLD] = (tk % rd.ratio) != (rd.ratio - 1) ? 1.0 : 0.0;   // constraintsVSMPC.cpp:351,366-372
     }
     __syncthreads();
-    if (lane < 3) {                                  // needs the reference window's first column
+    if (lane < 3) {                                  // QPInput::getPosCoMReference / getRPYReference = column 0 (costsVSMPC.cpp:155-156)
         r[VSMPC_IN_X0 + 20 + lane] = s[VSMPC_PS_P + lane] - r[VSMPC_IN_XREF + lane];
-        r[VSMPC_IN_X0 + 23 + lane] = s[VSMPC_PS_RPY + lane] - r[VSMPC_IN_XREF + 6 + lane];
+        r[VSMPC_IN_X0 + 23 + lane] = r[VSMPC_IN_X0 + 6 + lane] - r[VSMPC_IN_XREF + 6 + lane];
         r[VSMPC_IN_PREF + lane] = r[VSMPC_IN_XREF + lane];
     }
     __syncthreads();
@@ -162,17 +237,20 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
 __global__ __launch_bounds__(RO_BLOCK) void record_kernel(RolloutDev rd, int batch, const double* __restrict__ state,
                                                            const double* __restrict__ params, const int* __restrict__ tick,
                                                            const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
-                                                           const double* __restrict__ traj_alpha, double* __restrict__ rec) {
+                                                           const double* __restrict__ traj_alpha, double* __restrict__ tstate,
+                                                           double* __restrict__ rec) {
     __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], R[9], om[3];
-    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES];
+    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES], ts[12 * MAX_STAGES + 8];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
     stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
     stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
     __syncthreads();
-    assemble_record(rd, s, p, tick[b] + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, r, lane);
+    assemble_record(rd, s, p, tick[b] + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, true);
     double* out = rec + size_t(b) * rd.n_in;
     for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
+    double* tso = tstate + size_t(b) * rd.n_ts;
+    for (int e = lane; e < rd.n_ts; e += RO_BLOCK) tso[e] = ts[e];
 }
 
 // One wavefront per instance: staging and the joint-dependent jet map in parallel, the short ODE integration in lane 0
@@ -184,11 +262,13 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
                                                             const int* __restrict__ iters, const double* __restrict__ traj_alpha,
                                                             const RolloutCtl* __restrict__ ctl, int substeps,
                                                             const double* __restrict__ traj_pos,
-                                                            const double* __restrict__ traj_vel, double* __restrict__ rec_next) {
+                                                            const double* __restrict__ traj_vel, double* __restrict__ tstate,
+                                                            double* __restrict__ rec_next) {
     __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9], R[9], om[3];
-    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES];
+    __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES], ts[12 * MAX_STAGES + 8];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
+    for (int e = lane; e < rd.n_ts; e += RO_BLOCK) ts[e] = tstate[size_t(b) * rd.n_ts + e];
     stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
     stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
     stage_in<VSMPC_FM_SIZE>(fm + size_t(b) * VSMPC_FM_SIZE, f, lane);
@@ -196,7 +276,7 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
     const int tick_before = tick[b];
     // every global load of this kernel is requested as early as possible: each dependent round trip costs ~1.5 us
     double* const log = ctl->log;
-    const int tick_base = ctl->tick_base;
+    const int tick_base = ctl->tick_base, log_rows = ctl->log_rows;
     __syncthreads();
     __shared__ double alpha_s[16];   // alpha-gravity of every sub-step (one round trip instead of one per sub-step)
     if (lane >= 32 && lane < 32 + substeps && lane < 48) {
@@ -295,6 +375,7 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
     if (log != nullptr && lane < VSMPC_ROLLOUT_LOG) {
         const int row = tick_before - tick_base;   // ticks since the start of this run
         double v;
+        if (row < 0 || row >= log_rows) return;   // a run that failed half-way leaves the counters ahead: never write outside the log
         if (lane < 3) v = s[lane];
         else if (lane < 6) v = s[6 + lane - 3];
         else if (lane < 10) v = s[12 + lane - 6];
@@ -304,25 +385,28 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
         log[(size_t(row) * batch + b) * VSMPC_ROLLOUT_LOG + lane] = v;
     }
     if (rec_next != nullptr) {
-        assemble_record(rd, s, p, tick_before + 1 + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, r, lane);
+        assemble_record(rd, s, p, tick_before + 1 + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, false);
         double* out = rec_next + size_t(b) * rd.n_in;
         for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
+        double* tso = tstate + size_t(b) * rd.n_ts;
+        for (int e = lane; e < rd.n_ts; e += RO_BLOCK) tso[e] = ts[e];
     }
 }
 
 hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,
-                         const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* rec,
-                         hipStream_t stream) {
+                         const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* tstate,
+                         double* rec, hipStream_t stream) {
     hipLaunchKernelGGL(record_kernel, dim3(batch), dim3(RO_BLOCK), 0, stream, rd, batch, state, params, tick,
-                       traj_pos, traj_vel, traj_alpha, rec);
+                       traj_pos, traj_vel, traj_alpha, tstate, rec);
     return hipGetLastError();
 }
 
 hipError_t launch_advance(const RolloutDev& rd, int batch, double* state, const double* params, int* tick, const double* fm,
                           const int* status, const int* iters, const double* traj_alpha, const RolloutCtl* ctl, int substeps,
-                          const double* traj_pos, const double* traj_vel, double* rec_next, hipStream_t stream) {
+                          const double* traj_pos, const double* traj_vel, double* tstate, double* rec_next,
+                          hipStream_t stream) {
     hipLaunchKernelGGL(advance_kernel, dim3(batch), dim3(RO_BLOCK), 0, stream, rd, batch, state, params, tick, fm,
-                       status, iters, traj_alpha, ctl, substeps, traj_pos, traj_vel, rec_next);
+                       status, iters, traj_alpha, ctl, substeps, traj_pos, traj_vel, tstate, rec_next);
     return hipGetLastError();
 }
 

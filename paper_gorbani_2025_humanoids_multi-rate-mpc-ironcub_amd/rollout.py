@@ -70,7 +70,10 @@ def make_plant(cfg: L.MPCConfig, batch: int, *, workload: str = "hover", seed0: 
         t0 = tick0 * cfg.period_mpc
         if workload == "takeoff":
             alpha = alpha_gravity_profile(t0)
-            dp, dv = takeoff_profile(t0)
+            # start ON the reference the loop tracks at that tick: column 0 of the reference's FIFO window, i.e. the
+            # trajectory sample pushed one window length (10 columns = 1 s) earlier (costsVSMPC.cpp:121-165)
+            col0 = max(0, 1 + tick0 // cfg.ratio - (cfg.n_ref_cols - 1))
+            dp, dv = takeoff_profile(col0 * cfg.period_large)
         else:
             alpha, dp, dv = 1.0, np.zeros(3), np.zeros(3)
         rpy = rpy_init + rng.normal(0.0, 0.05 * sigma, size=3)

@@ -1,5 +1,6 @@
-"""numpy model of the closed-loop rollout kernels (vsmpc_rollout.hip): the record builder and the plant advance.
-Test infrastructure: the GPU rollout is checked against it tick by tick."""
+"""numpy model of the synthetic plant of the closed-loop rollout (vsmpc_rollout.hip): the kinematics-derived record fields
+and the plant advance.  The tick state machine is modelled in tests/tick_model.py from the reference's code.
+Test infrastructure: the GPU rollout is checked against both tick by tick."""
 from __future__ import annotations
 
 import importlib
@@ -38,28 +39,18 @@ def amom_of_q(s, p):
     return A + np.einsum("jrc,j->rc", DJ, dq), DJ
 
 
-def build_record(cfg, s, p, tick, traj_pos, traj_vel, traj_alpha, alpha_dt):
+def kin_record(cfg, s, p):
+    """The record fields that are functions of the current plant state alone (the kinematics provider's share of
+    IMPCProblem::update): R, omega, mass, gravity, A_mom(q), Lambda_lin/ang, I_G, linearisation thrusts.  The
+    tick-state fields (reference window, X0 errors, alpha, hold, unwrapped RPY, previous commands) come from
+    tests/tick_model.py, which is written from the reference's plugins."""
     rec = np.zeros(cfg.n_in)
-    tk = tick + int(p[L.PP_TICK0])
     R = rot(s[L.PS_RPY:L.PS_RPY + 3])
     IB = p[L.PP_INERTIA_B:L.PP_INERTIA_B + 9].reshape(3, 3)
     omega = np.linalg.solve(IB, s[L.PS_HANG:L.PS_HANG + 3])
-    m = p[L.PP_MASS]
-    idx0 = tk // cfg.ratio
-    xref = np.zeros((cfg.n_ref_cols, 12))
-    for j in range(cfg.n_ref_cols):
-        idx = min(idx0 + j, len(traj_pos) - 1)
-        xref[j, 0:3] = p[L.PP_PINIT:L.PP_PINIT + 3] + traj_pos[idx]
-        xref[j, 3:6] = R.T @ (m * traj_vel[idx])
-        xref[j, 6:9] = p[L.PP_RPYINIT:L.PP_RPYINIT + 3]
-    rec[L.IN_XREF:] = xref.reshape(-1)
-    rec[L.IN_X0:L.IN_X0 + 20] = s[0:20]
-    rec[L.IN_X0 + 20:L.IN_X0 + 23] = s[L.PS_P:L.PS_P + 3] - xref[0, 0:3]
-    rec[L.IN_X0 + 23:L.IN_X0 + 26] = s[L.PS_RPY:L.PS_RPY + 3] - xref[0, 6:9]
-    rec[L.IN_MASS] = m
+    rec[L.IN_MASS] = p[L.PP_MASS]
     rec[L.IN_WRB:L.IN_WRB + 9] = R.reshape(-1)
     rec[L.IN_OMEGA:L.IN_OMEGA + 3] = omega
-    rec[L.IN_ALPHA] = interp_clamped(traj_alpha, tk * cfg.period_mpc / alpha_dt)
     rec[L.IN_GRAV:L.IN_GRAV + 3] = [0.0, 0.0, -9.81]
     A, DJ = amom_of_q(s, p)
     T = s[L.PS_T:L.PS_T + 4]
@@ -68,17 +59,24 @@ def build_record(cfg, s, p, tick, traj_pos, traj_vel, traj_alpha, alpha_dt):
     rec[L.IN_LLIN:L.IN_LLIN + 24] = Lam[0:3].reshape(-1)
     rec[L.IN_LANG:L.IN_LANG + 24] = Lam[3:6].reshape(-1)
     rec[L.IN_INERTIA:L.IN_INERTIA + 9] = (R @ IB @ R.T).reshape(-1)
-    rec[L.IN_RPY:L.IN_RPY + 3] = s[L.PS_RPY:L.PS_RPY + 3]
-    rec[L.IN_PREF:L.IN_PREF + 3] = xref[0, 0:3]
-    rec[L.IN_RPYINIT:L.IN_RPYINIT + 3] = p[L.PP_RPYINIT:L.PP_RPYINIT + 3]
     rec[L.IN_T0:L.IN_T0 + 4] = T
     rec[L.IN_TD0:L.IN_TD0 + 4] = s[L.PS_TD:L.PS_TD + 4]
-    rec[L.IN_UPREV:L.IN_UPREV + 4] = s[L.PS_U:L.PS_U + 4]
-    rec[L.IN_TDES:L.IN_TDES + 4] = s[L.PS_TDES:L.PS_TDES + 4]
-    rec[L.IN_TDDES:L.IN_TDDES + 4] = s[L.PS_TDDES:L.PS_TDDES + 4]
-    rec[L.IN_QERR:L.IN_QERR + 8] = s[L.PS_Q:L.PS_Q + 8] - p[L.PP_QREF0:L.PP_QREF0 + 8]
-    rec[L.IN_HOLD] = 1.0 if (tk % cfg.ratio) != cfg.ratio - 1 else 0.0
     return rec
+
+
+def make_tick_model(cfg, s0, p, traj_pos, traj_vel, traj_alpha):
+    """Reference-derived tick state machine (tests/tick_model.py) for one instance of the synthetic plant: configured at
+    PP_PINIT / PP_RPYINIT, PP_TICK0 ticks already run (with the current attitude, as the device defines a mid-trajectory
+    start)."""
+    import tick_model
+    return tick_model.ReferenceTickModel(cfg, s0, p, traj_pos, traj_vel, traj_alpha, ticks_before=int(p[L.PP_TICK0]),
+                                         configured_elsewhere=True)
+
+
+def build_record(cfg, model, s, p):
+    """Record of the model's next update() on plant state `s` (advances the model's tick state)."""
+    import tick_model
+    return tick_model.record_from_tick(cfg, model.update(s), kin_record(cfg, s, p))
 
 
 def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5):

@@ -59,16 +59,62 @@ def test_model_closed_loop_with_oracle_holds_throttle(layout, ref):
     pos, vel, alpha, adt = ro.make_trajectory(cfg, "hover", 5.0)
     s, p = st[0].copy(), pa[0]
     tick0 = int(p[layout.PP_TICK0])
+    model = rm.make_tick_model(cfg, s, p, pos, vel, alpha)
     changes = []
     for tick in range(25):
-        rec = rm.build_record(cfg, s, p, tick, pos, vel, alpha, adt)
+        rec = rm.build_record(cfg, model, s, p)
         assert rec[layout.IN_HOLD] == (0.0 if (tick0 + tick) % cfg.ratio == cfg.ratio - 1 else 1.0)
         x, y, _, qp = ref.solve_instance(rcfg, rec)
         cert = ref.kkt_certificate(*qp, x, y)
         assert cert["stationarity_rel"] < 1e-9 and cert["primal"] < 1e-9
         u_before = s[layout.PS_U:layout.PS_U + 4].copy()
-        s = rm.advance(cfg, s, p, tick, ref.first_move_vector(rcfg, x), 1, alpha, adt)
+        fm = ref.first_move_vector(rcfg, x)
+        model.consume(fm, 1)
+        s = rm.advance(cfg, s, p, tick, fm, 1, alpha, adt)
         if np.abs(s[layout.PS_U:layout.PS_U + 4] - u_before).max() > 1e-9:
             changes.append((tick0 + tick) % cfg.ratio)
     assert changes and all(c == cfg.ratio - 1 for c in changes)
     assert np.isfinite(s).all() and np.abs(s[layout.PS_RPY:layout.PS_RPY + 3]).max() < 0.2
+
+
+def test_tick_model_follows_the_reference_call_counts(layout):
+    """The reference's own semantics, on the reference's own trajectory files (tests/golden/reference_trajectories.npz):
+    FIFO window with a 10-column lag, push on ticks k % 20 == 19 = the throttle-release ticks, h_lin column frozen with
+    the R of its push, alpha cursor one sample ahead (configure consumed sample 0), RPY unwrap across +-pi."""
+    import os
+    import tick_model as tm
+    ro, cfg = _rollout(), layout.paper_config()
+    pos, vel, alpha, adt = ro.load_reference_trajectories(os.path.join(ROOT, "tests", "golden", "reference_trajectories.npz"))
+    st, pa = ro.make_plant(cfg, 1, workload="hover", seed0=5)
+    s, p = st[0].copy(), pa[0].copy()
+    p[layout.PP_TICK0] = 0.0
+    p[layout.PP_PINIT:layout.PP_PINIT + 3] = s[layout.PS_P:layout.PS_P + 3]
+    s[layout.PS_RPY + 2] = np.pi - 0.01                      # yaw just below +pi
+    p[layout.PP_RPYINIT:layout.PP_RPYINIT + 3] = tm.as_rpy(s[layout.PS_RPY:layout.PS_RPY + 3])
+    m = tm.ReferenceTickModel(cfg, s, p, pos, vel, alpha)
+    n = cfg.n_ref_cols
+    up = tm.TrajectoryManager({"alphaGravity": alpha[None, :]}, 10, 200).trajectories_map["alphaGravity"].values
+    assert len(up) == 20 * (len(alpha) - 1)
+    pushes = []
+    for k in range(4200 + 45):
+        s_k = s.copy()
+        s_k[layout.PS_RPY + 2] += 0.001 * k                   # yaw drifts through +pi: wrapped measurement jumps by -2 pi
+        s_k[layout.PS_RPY] = 0.02 * np.sin(0.01 * k)          # roll wobbles: R differs from push to push
+        f = m.update(s_k)
+        assert f["hold"] == (0.0 if k % 20 == 19 else 1.0)                               # constraintsVSMPC.cpp:351-372
+        assert f["alpha"] == up[min(k + 1, len(up) - 1)][0]                              # systemDynamicsVSMPC.cpp:308-311
+        ns = 1 + (k + 1) // 20                                                           # shifts so far incl. configure
+        for j in range(n):
+            sj = ns - (n - 1 - j)
+            np.testing.assert_allclose(f["xref"][j, 0:3], p[layout.PP_PINIT:layout.PP_PINIT + 3] + pos[max(sj, 0)], rtol=0, atol=1e-15)
+        if k % 20 == 19:
+            pushes.append((k, f["xref"][-1, 3:6].copy(), tm.rot(s_k[layout.PS_RPY:layout.PS_RPY + 3])))
+        if len(pushes) >= 2:                                  # the column pushed one release earlier kept ITS rotation
+            k0, col, R0 = pushes[-2]
+            if k - k0 < 20 and np.abs(vel[1 + (k0 + 1) // 20]).max() > 0:
+                np.testing.assert_allclose(f["xref"][-2, 3:6], col, rtol=0, atol=0)
+                np.testing.assert_allclose(col, R0.T @ (p[layout.PP_MASS] * vel[1 + (k0 + 1) // 20]), rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(f["x0"][6:9], s_k[layout.PS_RPY:layout.PS_RPY + 3], rtol=0, atol=1e-12)   # unwrapped == continuous
+        assert np.abs(f["rpy"]).max() <= np.pi
+    assert m.init_state.m_nTurns[2] == 1                      # one turn counted at the crossing
+    assert m.cost.m_trajManager.trajectoryIndex == 1 + 4245 // 20

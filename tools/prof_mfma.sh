@@ -11,7 +11,7 @@ rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 run() {  # name, counters...
     local name=$1; shift
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- \
-        python3 bench.py --no-cpu-baseline --no-latency --no-extra --steps 20 --warmup 5 "${BARGS[@]}" > "$OUT/$name.json" 2> "$OUT/$name.err"
+        python3 bench.py --no-cpu-baseline --no-latency --no-extra --steps 10 --warmup 3 "${BARGS[@]}" > "$OUT/$name.json" 2> "$OUT/$name.err"
     local rc=$?
     echo "pass $name rc=$rc" | tee -a "$OUT/passes.txt"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
