@@ -18,6 +18,9 @@ EXPORTS = (
     "vsmpc_timing_end", "vsmpc_strerror", "vsmpc_kernel_name", "vsmpc_debug_phase_cycles", "vsmpc_kinematics_batch",
     "vsmpc_rollout_create", "vsmpc_rollout_destroy", "vsmpc_rollout_reset", "vsmpc_rollout_run",
     "vsmpc_rollout_get_state", "vsmpc_rollout_get_records", "vsmpc_alloc_host", "vsmpc_free_host",
+    # include/vsmpc_jet.h
+    "vsmpc_jet_create", "vsmpc_jet_destroy", "vsmpc_jet_nn_step", "vsmpc_jet_nn_sequence", "vsmpc_jet_ekf_update",
+    "vsmpc_jet_plant_run", "vsmpc_jet_plant_run_device",
 )
 
 _lib = None
@@ -83,6 +86,21 @@ def load():
     lib.vsmpc_alloc_host.restype = vp
     lib.vsmpc_free_host.argtypes = [vp]
     lib.vsmpc_free_host.restype = None
+    fp = ctypes.c_void_p
+    lib.vsmpc_jet_create.argtypes = [fp, fp, fp, fp, fp, fp, dp, c_int, c_int, c_int, ctypes.POINTER(vp)]
+    lib.vsmpc_jet_create.restype = c_int
+    lib.vsmpc_jet_destroy.argtypes = [vp]
+    lib.vsmpc_jet_destroy.restype = None
+    lib.vsmpc_jet_nn_step.argtypes = [vp, fp, fp, c_int, ctypes.c_float, fp, fp, fp, fp]
+    lib.vsmpc_jet_nn_step.restype = c_int
+    lib.vsmpc_jet_nn_sequence.argtypes = [vp, fp, c_int, c_int, ctypes.c_float, fp, fp, fp, fp]
+    lib.vsmpc_jet_nn_sequence.restype = c_int
+    lib.vsmpc_jet_ekf_update.argtypes = [vp, dp, dp, dp, dp, c_int, ctypes.c_double, dp, dp]
+    lib.vsmpc_jet_ekf_update.restype = c_int
+    lib.vsmpc_jet_plant_run.argtypes = [vp, fp, dp, dp, fp, c_int, c_int, c_int, ctypes.c_double, dp, dp, dp]
+    lib.vsmpc_jet_plant_run.restype = c_int
+    lib.vsmpc_jet_plant_run_device.argtypes = [vp, fp, dp, dp, fp, c_int, c_int, c_int, ctypes.c_double, dp, dp, dp, vp]
+    lib.vsmpc_jet_plant_run_device.restype = c_int
     lib.vsmpc_strerror.argtypes = [c_int]
     lib.vsmpc_strerror.restype = ctypes.c_char_p
     lib.vsmpc_kernel_name.argtypes = [vp]

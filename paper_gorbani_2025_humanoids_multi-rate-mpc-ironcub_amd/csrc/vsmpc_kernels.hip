@@ -385,7 +385,8 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
     }
     double dmin = 1.0;     // all pivots positive <=> min(pivots) > 0; a NaN pivot (fmin skips it) makes every later
                            // pivot and the last reciprocal square root NaN, which is checked at the end
-    double invs[NPIV];     // wave-uniform reciprocal square roots of the pivots
+    const bool keeps_invd = lane == 0 && (!SPLIT || w == 0);   // 1/L_jj goes to LDS as it is formed (no register array)
+    double inv_last = 1.0;
     // software-pipelined pivots: the next pivot is complete as soon as the first column of this pivot's update is
     // done, so its reciprocal square root (a ~75-cycle dependent chain) is issued there and overlaps the rest of the
     // update instead of following it
@@ -394,7 +395,8 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll
     for (int j = 0; j < NPIV; ++j) {
         dmin = fmin(dmin, d);
-        invs[j] = inv;
+        if (keeps_invd) sInvD[16 * p + j] = inv;
+        inv_last = inv;
         double l[NSLOT];
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) { l[s] = a[s][j] * inv; a[s][j] = l[s]; }
@@ -428,11 +430,7 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll
             for (int c = 0; c < 16; ++c) T[s][c] = a[s][c];
         }
-    if (lane == 0 && (!SPLIT || w == 0)) {
-#pragma unroll
-        for (int j = 0; j < NPIV; ++j) sInvD[16 * p + j] = invs[j];
-    }
-    return !(dmin > 0.0) || !(invs[NPIV - 1] == invs[NPIV - 1]);
+    return !(dmin > 0.0) || !(inv_last == inv_last);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -746,7 +744,7 @@ VS_DEV double small_spd_solve(const double* __restrict__ sP, unsigned long long 
 }
 
 // size dispatch for small_spd_solve (one straight-line instantiation per size)
-constexpr int SMALL_SOLVE_MAX = 8;
+constexpr int SMALL_SOLVE_MAX = 6;
 // block principal pivoting: non-improving block steps tolerated before the least-index fallback (the oracle's value)
 constexpr int AS_PATIENCE = 10;
 constexpr int AS_MAX_ITER = 64;   // active-set iteration cap (status MAX_ITER beyond)
@@ -778,6 +776,348 @@ VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec,
         sr = fma(c <= r ? lrc : 0.0, ellc, sr);
     }
     if (lane < D::NV) sSvec[r] = sr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P4b: box QP on the throttles (constraintsVSMPC.cpp:338-365), entered only by instances whose pins-only solution violates
+// a bound.  Kept small in registers (K x K systems up to 6 x 6 in registers, columns of X re-read from LDS): the
+// accumulator tiles are live across it, and what it cannot hold gets spilled for every instance.  (Out of line as a
+// real call it costs the slowest instance of a launch ~4 us in saved / restored registers.)  Few saturated throttles (the usual case): dual
+// form, cost grows with the number of active bounds; many: primal form on the Schur complement, cost grows with the
+// number of free throttles.  Called by all wavefronts (it contains workgroup barriers); result in sZ[NU..NZ), sFlags.
+// ------------------------------------------------------------------------------------------------
+template <class D>
+VS_DEV void box_qp(int n_violated, bool hold) {
+    using S = Smem<D>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sVprev = smem + S::oVprev;
+    double* sInvD = smem + S::oInvD;
+    double* sZ = smem + S::oZ;
+    double* sSv = smem + S::oSv;
+    double* sSvec = smem + S::oSvec;
+    double* sCfg = smem + S::oCfg;
+    int* sFlags = reinterpret_cast<int*>(smem + S::oFlags);
+    double* Lb = smem + S::oM;
+    double* sXinv = smem + S::oXinv;
+    double* sQP = smem + S::oQP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool DUALQP = S::DUALQP;
+    constexpr int PV = D::PVT;
+    constexpr int DUAL_MAX_ACTIVE = 10;
+    const bool use_dual = DUALQP && n_violated <= DUAL_MAX_ACTIVE;
+    (void)sQP; (void)sXinv; (void)sInvD;
+      if (use_dual) {
+       if constexpr (DUALQP) {
+        // ---- box QP on the throttles, dual form.  With N = the throttles that are not pinned by the hold, P = S_NN^-1
+        // (S = L22 L22^T, so the factor of S_NN is the leading block of L22) and v_u = the sweep's solution, fixing the
+        // set A at its bounds b_A gives  mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.
+        // P = X^T X with X = L22^-1: rows 0..15 of X are the inverse of the first throttle diagonal tile (formed by an
+        // idle wavefront during P3), the remaining rows are formed here; a column of P then is 24 multiply-adds per
+        // lane with no chain, and only the columns some active set needs are ever formed.  The |A| x |A| system is
+        // tiny for the usual one to three saturated throttles.  The sequence of active sets is exactly the
+        // block-pivoting sequence of the primal form.
+        {
+            // second tile row of X by all wavefronts:  [X76 | X77] = [-X77 (L76 X66) | L77^-1]
+            constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
+            double* sXr = sQP + D::NV * NVS;                              // sXr[a * NVS + j] = X[16 + a][j]
+            double* sT = sQP;                                             // T = L76 X66, NR2 x 16 (dead before sK is used)
+            const double* X6 = sXinv + PV * D::TS;
+            const double* L76 = Lb + tile_off<D>(PV + 1, PV);
+            const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
+            if (tid < 16 * NR2) {
+                const int a2 = tid >> 4, j = tid & 15;
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {                         // X66[k][j] = 0 for k < j (stored zeros)
+                    t0 = fma(L76[a2 * 17 + k], X6[k * 17 + j], t0);
+                    t1 = fma(L76[a2 * 17 + k + 1], X6[(k + 1) * 17 + j], t1);
+                }
+                sT[a2 * 16 + j] = t0 + t1;
+            } else if (tid >= 128 && tid < 128 + NR2) {
+                const int c = tid - 128;                                  // column c of X77 = L77^-1
+                double x[NR2];
+#pragma unroll
+                for (int i = 0; i < NR2; ++i) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; ++k) sum = fma(L77[i * 17 + k], (k >= c) ? x[k] : 0.0, sum);
+                    const double di = sInvD[D::NU + 16 + i];
+                    x[i] = (i == c) ? di : ((i > c) ? -di * sum : 0.0);
+                    sXr[i * NVS + 16 + c] = x[i];
+                }
+            } else if (wave == 3) {
+                schur_rhs<D>(Lb, sSvec, lane);
+            }
+            __syncthreads();
+            if (wave == 3) {  // max |s| while wavefronts 0..1 finish X (keeps it off wavefront 0's path)
+                double gm = 0.0;
+#pragma unroll
+                for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
+                if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
+            }
+            if (tid < 16 * NR2) {
+                const int a2 = tid >> 4, j = tid & 15;
+                double t = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < NR2; ++b2) t = fma(sXr[a2 * NVS + 16 + b2], sT[b2 * 16 + j], t);  // X77[a][b] = 0, b > a
+                sXr[a2 * NVS + j] = -t;
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
+            constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
+            constexpr int NR2 = D::NV - 16;         // throttle rows in the second tile row
+            double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
+            double* sK = sQP;                       // working copy of P_AA
+            double* sXr = sQP + D::NV * NVS;        // rows 16.. of X: sXr[a * NVS + j] = X[16 + a][j]
+            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
+            const bool valid = lane < D::NV;
+            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
+            const int n = hold ? D::NV - 4 : D::NV;
+            const bool inN = valid && r < n;
+            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
+            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
+            const double* X6 = sXinv + PV * D::TS;  // X[i][j], i, j < 16, at i*17 + j; rows 16.. are in sXr (sweep_tile)
+            const double gtol = 1e-10 * (1.0 + sSvec[0]);   // sSvec[0] = max |s| (see above)
+            const double vu = sZ[D::NU + r];
+            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
+            // backward sweep that just ran.  Apply its flips here; nothing is at a bound yet, so only primal
+            // violations can occur.
+            int state = 0;  // 0 free, -1 at lower, +1 at upper (pinned throttles are outside N altogether)
+            double v = vu;
+            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
+            {
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool vlo = inN && (v < lo - tolv);
+                const bool vhi = inN && (v > hi + tolv);
+                best = __popcll(__ballot(vlo || vhi));
+                if (vlo || vhi) state = vlo ? -1 : 1;
+            }
+            // column r of X restricted to the rows of N (this lane's factor of every P entry it forms): re-read from LDS
+            // where it is used (lane-contiguous addresses) instead of held in 2 NV registers -- with the accumulator
+            // tiles live through P4 the box QP must stay small in registers, or tiles get spilled for EVERY instance
+            auto xc = [&](int j) -> double {
+                const double t = j < 16 ? X6[j * 17 + (r & 15)] : sXr[(j - 16) * NVS + r];
+                return (j < 16 ? r < 16 : j < n) ? t : 0.0;
+            };
+            unsigned long long have = 0ull;
+            for (int it = 1; it < AS_MAX_ITER; ++it) {
+                iters = it + 1;
+                const bool isA = inN && state != 0;
+                const unsigned long long Amask = __ballot(isA);
+                // columns of P for the newly active throttles: P[i][b] = sum_{j < n} X[j][i] X[j][b]
+                unsigned long long need = Amask & ~have;
+                have |= need;
+                while (need) {
+                    const int b = __ffsll((long long)need) - 1;
+                    need &= need - 1;
+                    double p0 = 0.0, p1 = 0.0;
+                    if (b < 16) {  // X[j][b] = 0 for j < 16 <= b
+#pragma unroll
+                        for (int j = 0; j < 16; j += 2) {
+                            p0 = fma(xc(j), X6[j * 17 + b], p0);            // uniform addresses: LDS broadcasts
+                            p1 = fma(xc(j + 1), X6[(j + 1) * 17 + b], p1);
+                        }
+                    }
+#pragma unroll
+                    for (int a2 = 0; a2 < NR2; ++a2) p0 = fma(xc(16 + a2), sXr[a2 * NVS + b], p0);
+                    if (valid) sP[b * NVS + r] = p0 + p1;
+                }
+                double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
+                double mu = 0.0;
+                const int ka = __popcll(Amask);
+                if (ka == 0) {
+                    // every bound was released again: v = v_u, no multipliers
+                } else if (ka <= SMALL_SOLVE_MAX) {
+                    // few active bounds: solved redundantly in every lane on wave-uniform values
+                    mu = small_spd_solve_n<D::NV + 1>(ka, sP, Amask, bb, lane, bad);
+                } else {
+                    // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
+                    if (isA) {
+                        unsigned long long m = Amask;
+                        while (m) {
+                            const int c = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            sK[r * NVS + c] = sP[c * NVS + r];
+                        }
+                    }
+                    for (unsigned long long pm = Amask; pm; pm &= pm - 1) {
+                        const int j = __ffsll((long long)pm) - 1;
+                        const double piv = sK[j * NVS + j];
+                        bad |= !(piv > 0.0);
+                        const double bj = readlane_f64(bb, j);
+                        if (isA && lane > j) {
+                            const double f = sK[r * NVS + j] * fast_rcp(piv);
+                            bb -= f * bj;
+                            for (unsigned long long m = pm & (pm - 1); m; m &= m - 1) {
+                                const int c = __ffsll((long long)m) - 1;
+                                sK[r * NVS + c] -= f * sK[j * NVS + c];
+                            }
+                        }
+                    }
+                    for (unsigned long long pm = Amask; pm;) {
+                        const int j = 63 - __clzll((long long)pm);
+                        pm &= ~(1ull << j);
+                        const double xj = readlane_f64(bb, j) * fast_rcp(sK[j * NVS + j]);
+                        if (lane == j) mu = xj;
+                        if (isA && lane < j) bb -= sK[r * NVS + j] * xj;
+                    }
+                }
+                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
+                // v_N = v_u,N - P[:,A] mu
+                v = vu;
+                for (unsigned long long m = Amask; m; m &= m - 1) {
+                    const int b = __ffsll((long long)m) - 1;
+                    const double mub = readlane_f64(mu, b);
+                    if (inN) v -= sP[b * NVS + r] * mub;
+                }
+                const double grad = -mu;  // gradient of the QP at the throttles that sit on a bound
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool isF = inN && state == 0;
+                const bool vlo = isF && (v < lo - tolv);
+                const bool vhi = isF && (v > hi + tolv);
+                const bool rlo = isA && state == -1 && grad < -gtol;
+                const bool rhi = isA && state == 1 && grad > gtol;
+                const bool inf = vlo || vhi || rlo || rhi;
+                const unsigned long long imask = __ballot(inf);
+                const int ninf = __popcll(imask);
+                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
+                bool pick = inf;
+                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
+                else if (patience > 0) { --patience; }
+                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
+                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
+            }
+            if (valid) {
+                v = fixed ? lo : (state < 0 ? lo : (state > 0 ? hi : v));  // bound variables sit exactly on their bound
+                sZ[D::NU + lane] = v;
+            }
+            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+        }
+       }
+      } else {
+        // Schur complement S = L22 L22^T, s = L22 (L^-1 g)_v
+        for (int e = tid; e < D::NV * D::NV; e += D::BLOCK) {
+            const int r = e / D::NV, c = e % D::NV;
+            const int kmax = r < c ? r : c;
+            double sum = 0.0;
+            for (int k = 0; k <= kmax; ++k)
+                sum += Lb[lower_at<D>(D::NU + r, D::NU + k)] * Lb[lower_at<D>(D::NU + c, D::NU + k)];
+            sSv[r * (D::NV + 1) + c] = sum;
+        }
+        if (tid < D::NV) {
+            double sum = 0.0;
+            for (int k = 0; k <= tid; ++k)
+                sum += Lb[lower_at<D>(D::NU + tid, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
+            sSvec[tid] = sum;
+        }
+        __syncthreads();
+
+        if (wave == 0) {
+            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
+            const bool valid = lane < D::NV;
+            double row[D::NV];
+#pragma unroll
+            for (int c = 0; c < D::NV; ++c) row[c] = sSv[r * (D::NV + 1) + c];
+            const double svr = sSvec[r];
+            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
+            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
+            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
+            int state = fixed ? -1 : 0;  // 0 free, -1 at lower, +1 at upper
+            double gmax = fabs(svr);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
+            const double gtol = 1e-10 * (1.0 + gmax);
+            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
+            // backward sweep that just ran (its throttles are in sZ).  Apply its flips here instead of repeating
+            // the solve; nothing is at a bound yet, so only primal violations can occur.
+            double v = sZ[D::NU + r];
+            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1;
+            {
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool vlo = valid && state == 0 && (v < lo - tolv);
+                const bool vhi = valid && state == 0 && (v > hi + tolv);
+                best = __popcll(__ballot(vlo || vhi));
+                if (vlo || vhi) state = vlo ? -1 : 1;
+            }
+            for (int it = 1; it < AS_MAX_ITER; ++it) {
+                iters = it + 1;
+                const bool isF = valid && state == 0;
+                const unsigned long long Fmask = __ballot(isF);
+                const double vb = isF ? 0.0 : (state < 0 ? lo : hi);
+                double a[D::NV];
+                double b = isF ? -svr : vb;
+#pragma unroll
+                for (int c = 0; c < D::NV; ++c) {
+                    const bool cF = (Fmask >> c) & 1ull;
+                    const double vbc = readlane_f64(vb, c);
+                    if (isF && !cF) b -= row[c] * vbc;
+                    a[c] = (isF && cF) ? row[c] : ((c == r && !isF) ? 1.0 : 0.0);
+                }
+                int bad = 0;
+                const int nfree = __popcll(Fmask);
+                if (nfree >= 1 && nfree <= SMALL_SOLVE_MAX) {
+                    // deep saturation leaves few free throttles: S_FF v_F = b_F redundantly in registers on
+                    // wave-uniform values (S is symmetric: sSv[c * (NV+1) + i] = S[i][c], the layout the solver reads)
+                    const double vf = small_spd_solve_n<D::NV + 1>(nfree, sSv, Fmask, b, lane, bad);
+                    v = isF ? vf : vb;
+                } else {
+                // Gaussian elimination without pivoting (SPD), pivot rows broadcast with v_readlane.  Rows of bound
+                // throttles are identity rows whose column is zero elsewhere: their pivots are no-ops and are skipped
+                // (wave-uniform branch), so the cost follows the number of free throttles
+#pragma unroll
+                for (int j = 0; j < D::NV; ++j) {
+                    if ((Fmask >> j) & 1ull) {
+                        const double piv = readlane_f64(a[j], j);
+                        bad |= !(piv > 0.0);
+                        const double f = (lane > j) ? a[j] * fast_rcp(piv) : 0.0;
+                        const double bj = readlane_f64(b, j);
+                        b -= f * bj;
+#pragma unroll
+                        for (int c = j + 1; c < D::NV; ++c) {
+                            const double pc = readlane_f64(a[c], j);
+                            a[c] -= f * pc;
+                        }
+                    }
+                }
+                v = vb;  // bound throttles; free ones follow from the back-substitution
+#pragma unroll
+                for (int j = D::NV - 1; j >= 0; --j) {
+                    if ((Fmask >> j) & 1ull) {
+                        const double xj = readlane_f64(b, j) * fast_rcp(readlane_f64(a[j], j));
+                        if (lane == j) v = xj;
+                        if (lane < j) b -= a[j] * xj;
+                    }
+                }
+                }
+                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
+                double grad = svr;
+#pragma unroll
+                for (int c = 0; c < D::NV; ++c) grad += row[c] * readlane_f64(v, c);
+                const double tolv = 1e-12 * (1.0 + fabs(v));
+                const bool vlo = isF && (v < lo - tolv);
+                const bool vhi = isF && (v > hi + tolv);
+                const bool rlo = valid && state == -1 && !fixed && grad < -gtol;
+                const bool rhi = valid && state == 1 && !fixed && grad > gtol;
+                const bool inf = vlo || vhi || rlo || rhi;
+                const unsigned long long imask = __ballot(inf);
+                const int ninf = __popcll(imask);
+                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
+                bool pick = inf;
+                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
+                else if (patience > 0) { --patience; }
+                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
+                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
+            }
+            if (valid) {
+                v = state < 0 ? lo : (state > 0 ? hi : v);  // bound variables sit exactly on their bound
+                sZ[D::NU + lane] = v;
+            }
+            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+        }
+      }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1314,322 +1654,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(5);
     VS_REFRESH_IDS();
 
-    // few saturated throttles (the usual case): dual form, cost grows with the number of active bounds;
-    // many: primal form on the Schur complement, cost grows with the number of free throttles
-    constexpr int DUAL_MAX_ACTIVE = 10;
-    const bool use_dual = DUALQP && sFlags[3] <= DUAL_MAX_ACTIVE;
     if (need_qp) {
-      if (use_dual) {
-       if constexpr (DUALQP) {
-        // ---- box QP on the throttles, dual form.  With N = the throttles that are not pinned by the hold, P = S_NN^-1
-        // (S = L22 L22^T, so the factor of S_NN is the leading block of L22) and v_u = the sweep's solution, fixing the
-        // set A at its bounds b_A gives  mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.
-        // P = X^T X with X = L22^-1: rows 0..15 of X are the inverse of the first throttle diagonal tile (formed by an
-        // idle wavefront during P3), the remaining rows are formed here; a column of P then is 24 multiply-adds per
-        // lane with no chain, and only the columns some active set needs are ever formed.  The |A| x |A| system is
-        // tiny for the usual one to three saturated throttles.  The sequence of active sets is exactly the
-        // block-pivoting sequence of the primal form.
-        {
-            // second tile row of X by all wavefronts:  [X76 | X77] = [-X77 (L76 X66) | L77^-1]
-            constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
-            double* sXr = sQP + D::NV * NVS;                              // sXr[a * NVS + j] = X[16 + a][j]
-            double* sT = sQP;                                             // T = L76 X66, NR2 x 16 (dead before sK is used)
-            const double* X6 = sXinv + PV * D::TS;
-            const double* L76 = Lb + tile_off<D>(PV + 1, PV);
-            const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
-            if (tid < 16 * NR2) {
-                const int a2 = tid >> 4, j = tid & 15;
-                double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; k += 2) {                         // X66[k][j] = 0 for k < j (stored zeros)
-                    t0 = fma(L76[a2 * 17 + k], X6[k * 17 + j], t0);
-                    t1 = fma(L76[a2 * 17 + k + 1], X6[(k + 1) * 17 + j], t1);
-                }
-                sT[a2 * 16 + j] = t0 + t1;
-            } else if (tid >= 128 && tid < 128 + NR2) {
-                const int c = tid - 128;                                  // column c of X77 = L77^-1
-                double x[NR2];
-#pragma unroll
-                for (int i = 0; i < NR2; ++i) {
-                    double sum = 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; ++k) sum = fma(L77[i * 17 + k], (k >= c) ? x[k] : 0.0, sum);
-                    const double di = sInvD[D::NU + 16 + i];
-                    x[i] = (i == c) ? di : ((i > c) ? -di * sum : 0.0);
-                    sXr[i * NVS + 16 + c] = x[i];
-                }
-            } else if (wave == 3) {
-                schur_rhs<D>(Lb, sSvec, lane);
-            }
-            __syncthreads();
-            if (wave == 3) {  // max |s| while wavefronts 0..1 finish X (keeps it off wavefront 0's path)
-                double gm = 0.0;
-#pragma unroll
-                for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
-                if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
-            }
-            if (tid < 16 * NR2) {
-                const int a2 = tid >> 4, j = tid & 15;
-                double t = 0.0;
-#pragma unroll
-                for (int b2 = 0; b2 < NR2; ++b2) t = fma(sXr[a2 * NVS + 16 + b2], sT[b2 * 16 + j], t);  // X77[a][b] = 0, b > a
-                sXr[a2 * NVS + j] = -t;
-            }
-            __syncthreads();
-        }
-        if (wave == 0) {
-            static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
-            constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
-            constexpr int NR2 = D::NV - 16;         // throttle rows in the second tile row
-            double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
-            double* sK = sQP;                       // working copy of P_AA
-            double* sXr = sQP + D::NV * NVS;        // rows 16.. of X: sXr[a * NVS + j] = X[16 + a][j]
-            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
-            const bool valid = lane < D::NV;
-            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
-            const int n = hold ? D::NV - 4 : D::NV;
-            const bool inN = valid && r < n;
-            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
-            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
-            const double* X6 = sXinv + PV * D::TS;  // X[i][j], i, j < 16, at i*17 + j; rows 16.. are in sXr (sweep_tile)
-            const double gtol = 1e-10 * (1.0 + sSvec[0]);   // sSvec[0] = max |s| (see above)
-            const double vu = sZ[D::NU + r];
-            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
-            // backward sweep that just ran.  Apply its flips here; nothing is at a bound yet, so only primal
-            // violations can occur.
-            int state = 0;  // 0 free, -1 at lower, +1 at upper (pinned throttles are outside N altogether)
-            double v = vu;
-            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
-            {
-                const double tolv = 1e-12 * (1.0 + fabs(v));
-                const bool vlo = inN && (v < lo - tolv);
-                const bool vhi = inN && (v > hi + tolv);
-                best = __popcll(__ballot(vlo || vhi));
-                if (vlo || vhi) state = vlo ? -1 : 1;
-            }
-            // column r of X restricted to the rows of N (this lane's factor of every P entry it forms)
-            double xc[D::NV];
-#pragma unroll
-            for (int j = 0; j < D::NV; ++j) {
-                const double t = j < 16 ? X6[j * 17 + (r & 15)] : sXr[(j - 16) * NVS + r];
-                xc[j] = (j < 16 ? r < 16 : j < n) ? t : 0.0;
-            }
-            unsigned long long have = 0ull;
-            for (int it = 1; it < AS_MAX_ITER; ++it) {
-                iters = it + 1;
-                const bool isA = inN && state != 0;
-                const unsigned long long Amask = __ballot(isA);
-                // columns of P for the newly active throttles: P[i][b] = sum_{j < n} X[j][i] X[j][b]
-                unsigned long long need = Amask & ~have;
-                have |= need;
-                while (need) {
-                    const int b = __ffsll((long long)need) - 1;
-                    need &= need - 1;
-                    double p0 = 0.0, p1 = 0.0;
-                    if (b < 16) {  // X[j][b] = 0 for j < 16 <= b
-#pragma unroll
-                        for (int j = 0; j < 16; j += 2) {
-                            p0 = fma(xc[j], X6[j * 17 + b], p0);            // uniform addresses: LDS broadcasts
-                            p1 = fma(xc[j + 1], X6[(j + 1) * 17 + b], p1);
-                        }
-                    }
-#pragma unroll
-                    for (int a2 = 0; a2 < NR2; ++a2) p0 = fma(xc[16 + a2], sXr[a2 * NVS + b], p0);
-                    if (valid) sP[b * NVS + r] = p0 + p1;
-                }
-                double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
-                double mu = 0.0;
-                const int ka = __popcll(Amask);
-                if (ka == 0) {
-                    // every bound was released again: v = v_u, no multipliers
-                } else if (ka <= SMALL_SOLVE_MAX) {
-                    // few active bounds: solved redundantly in every lane on wave-uniform values
-                    mu = small_spd_solve_n<D::NV + 1>(ka, sP, Amask, bb, lane, bad);
-                } else {
-                    // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
-                    if (isA) {
-                        unsigned long long m = Amask;
-                        while (m) {
-                            const int c = __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            sK[r * NVS + c] = sP[c * NVS + r];
-                        }
-                    }
-                    for (unsigned long long pm = Amask; pm; pm &= pm - 1) {
-                        const int j = __ffsll((long long)pm) - 1;
-                        const double piv = sK[j * NVS + j];
-                        bad |= !(piv > 0.0);
-                        const double bj = readlane_f64(bb, j);
-                        if (isA && lane > j) {
-                            const double f = sK[r * NVS + j] * fast_rcp(piv);
-                            bb -= f * bj;
-                            for (unsigned long long m = pm & (pm - 1); m; m &= m - 1) {
-                                const int c = __ffsll((long long)m) - 1;
-                                sK[r * NVS + c] -= f * sK[j * NVS + c];
-                            }
-                        }
-                    }
-                    for (unsigned long long pm = Amask; pm;) {
-                        const int j = 63 - __clzll((long long)pm);
-                        pm &= ~(1ull << j);
-                        const double xj = readlane_f64(bb, j) * fast_rcp(sK[j * NVS + j]);
-                        if (lane == j) mu = xj;
-                        if (isA && lane < j) bb -= sK[r * NVS + j] * xj;
-                    }
-                }
-                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
-                // v_N = v_u,N - P[:,A] mu
-                v = vu;
-                for (unsigned long long m = Amask; m; m &= m - 1) {
-                    const int b = __ffsll((long long)m) - 1;
-                    const double mub = readlane_f64(mu, b);
-                    if (inN) v -= sP[b * NVS + r] * mub;
-                }
-                const double grad = -mu;  // gradient of the QP at the throttles that sit on a bound
-                const double tolv = 1e-12 * (1.0 + fabs(v));
-                const bool isF = inN && state == 0;
-                const bool vlo = isF && (v < lo - tolv);
-                const bool vhi = isF && (v > hi + tolv);
-                const bool rlo = isA && state == -1 && grad < -gtol;
-                const bool rhi = isA && state == 1 && grad > gtol;
-                const bool inf = vlo || vhi || rlo || rhi;
-                const unsigned long long imask = __ballot(inf);
-                const int ninf = __popcll(imask);
-                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
-                bool pick = inf;
-                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
-                else if (patience > 0) { --patience; }
-                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
-                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
-            }
-            if (valid) {
-                v = fixed ? lo : (state < 0 ? lo : (state > 0 ? hi : v));  // bound variables sit exactly on their bound
-                sZ[D::NU + lane] = v;
-            }
-            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
-        }
-       }
-      } else {
-        // Schur complement S = L22 L22^T, s = L22 (L^-1 g)_v
-        for (int e = tid; e < D::NV * D::NV; e += D::BLOCK) {
-            const int r = e / D::NV, c = e % D::NV;
-            const int kmax = r < c ? r : c;
-            double sum = 0.0;
-            for (int k = 0; k <= kmax; ++k)
-                sum += Lb[lower_at<D>(D::NU + r, D::NU + k)] * Lb[lower_at<D>(D::NU + c, D::NU + k)];
-            sSv[r * (D::NV + 1) + c] = sum;
-        }
-        if (tid < D::NV) {
-            double sum = 0.0;
-            for (int k = 0; k <= tid; ++k)
-                sum += Lb[lower_at<D>(D::NU + tid, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
-            sSvec[tid] = sum;
-        }
-        __syncthreads();
-
-        if (wave == 0) {
-            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
-            const bool valid = lane < D::NV;
-            double row[D::NV];
-#pragma unroll
-            for (int c = 0; c < D::NV; ++c) row[c] = sSv[r * (D::NV + 1) + c];
-            const double svr = sSvec[r];
-            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
-            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
-            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
-            int state = fixed ? -1 : 0;  // 0 free, -1 at lower, +1 at upper
-            double gmax = fabs(svr);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o));
-            const double gtol = 1e-10 * (1.0 + gmax);
-            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
-            // backward sweep that just ran (its throttles are in sZ).  Apply its flips here instead of repeating
-            // the solve; nothing is at a bound yet, so only primal violations can occur.
-            double v = sZ[D::NU + r];
-            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1;
-            {
-                const double tolv = 1e-12 * (1.0 + fabs(v));
-                const bool vlo = valid && state == 0 && (v < lo - tolv);
-                const bool vhi = valid && state == 0 && (v > hi + tolv);
-                best = __popcll(__ballot(vlo || vhi));
-                if (vlo || vhi) state = vlo ? -1 : 1;
-            }
-            for (int it = 1; it < AS_MAX_ITER; ++it) {
-                iters = it + 1;
-                const bool isF = valid && state == 0;
-                const unsigned long long Fmask = __ballot(isF);
-                const double vb = isF ? 0.0 : (state < 0 ? lo : hi);
-                double a[D::NV];
-                double b = isF ? -svr : vb;
-#pragma unroll
-                for (int c = 0; c < D::NV; ++c) {
-                    const bool cF = (Fmask >> c) & 1ull;
-                    const double vbc = readlane_f64(vb, c);
-                    if (isF && !cF) b -= row[c] * vbc;
-                    a[c] = (isF && cF) ? row[c] : ((c == r && !isF) ? 1.0 : 0.0);
-                }
-                int bad = 0;
-                const int nfree = __popcll(Fmask);
-                if (nfree >= 1 && nfree <= SMALL_SOLVE_MAX) {
-                    // deep saturation leaves few free throttles: S_FF v_F = b_F redundantly in registers on
-                    // wave-uniform values (S is symmetric: sSv[c * (NV+1) + i] = S[i][c], the layout the solver reads)
-                    const double vf = small_spd_solve_n<D::NV + 1>(nfree, sSv, Fmask, b, lane, bad);
-                    v = isF ? vf : vb;
-                } else {
-                // Gaussian elimination without pivoting (SPD), pivot rows broadcast with v_readlane.  Rows of bound
-                // throttles are identity rows whose column is zero elsewhere: their pivots are no-ops and are skipped
-                // (wave-uniform branch), so the cost follows the number of free throttles
-#pragma unroll
-                for (int j = 0; j < D::NV; ++j) {
-                    if ((Fmask >> j) & 1ull) {
-                        const double piv = readlane_f64(a[j], j);
-                        bad |= !(piv > 0.0);
-                        const double f = (lane > j) ? a[j] * fast_rcp(piv) : 0.0;
-                        const double bj = readlane_f64(b, j);
-                        b -= f * bj;
-#pragma unroll
-                        for (int c = j + 1; c < D::NV; ++c) {
-                            const double pc = readlane_f64(a[c], j);
-                            a[c] -= f * pc;
-                        }
-                    }
-                }
-                v = vb;  // bound throttles; free ones follow from the back-substitution
-#pragma unroll
-                for (int j = D::NV - 1; j >= 0; --j) {
-                    if ((Fmask >> j) & 1ull) {
-                        const double xj = readlane_f64(b, j) * fast_rcp(readlane_f64(a[j], j));
-                        if (lane == j) v = xj;
-                        if (lane < j) b -= a[j] * xj;
-                    }
-                }
-                }
-                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
-                double grad = svr;
-#pragma unroll
-                for (int c = 0; c < D::NV; ++c) grad += row[c] * readlane_f64(v, c);
-                const double tolv = 1e-12 * (1.0 + fabs(v));
-                const bool vlo = isF && (v < lo - tolv);
-                const bool vhi = isF && (v > hi + tolv);
-                const bool rlo = valid && state == -1 && !fixed && grad < -gtol;
-                const bool rhi = valid && state == 1 && !fixed && grad > gtol;
-                const bool inf = vlo || vhi || rlo || rhi;
-                const unsigned long long imask = __ballot(inf);
-                const int ninf = __popcll(imask);
-                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
-                bool pick = inf;
-                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
-                else if (patience > 0) { --patience; }
-                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
-                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
-            }
-            if (valid) {
-                v = state < 0 ? lo : (state > 0 ? hi : v);  // bound variables sit exactly on their bound
-                sZ[D::NU + lane] = v;
-            }
-            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
-        }
-      }
+        box_qp<D>(sFlags[3], hold);
         __syncthreads();
         VS_STAMP(6);
         VS_REFRESH_IDS();

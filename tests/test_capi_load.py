@@ -10,9 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
-    text = open(os.path.join(ROOT, "include", "vsmpc.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vsmpc_[a-z_]+)\s*\(", text)))
+    """every function any header under include/ declares (vsmpc.h: the MPC path, vsmpc_jet.h: the jet plant side)"""
+    names = set()
+    for header in ("vsmpc.h", "vsmpc_jet.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(vsmpc_[a-z_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_build_and_exports(solver_mod, pkg):
@@ -51,6 +55,14 @@ def test_strerror_and_arg_validation_without_gpu(solver_mod, pkg, layout):
     lib = _lib.load()
     assert lib.vsmpc_strerror(0) == b"ok"
     assert b"unsupported" in lib.vsmpc_strerror(-2)
+    # argument checks that need no device: NULL handles / pointers, negative sizes
+    assert lib.vsmpc_solve_batch_device(None, None, 4, None, None, None, None, None) == -1
+    assert lib.vsmpc_solve_batch(None, None, 4, None, None, None, None, None) == -1
+    assert lib.vsmpc_kinematics_batch(None, None, 1, None, None) == -1
+    assert lib.vsmpc_rollout_run(None, 5, None, None) == -1
+    assert lib.vsmpc_jet_nn_step(None, None, None, 3, 0.001, None, None, None, None) == -1
+    hj = ctypes.c_void_p()
+    assert lib.vsmpc_jet_create(None, None, None, None, None, None, None, 80, 0, 16, ctypes.byref(hj)) == -1
     h = ctypes.c_void_p()
     bad = layout.MPCConfig(n_iter=1).to_c()
     assert lib.vsmpc_create(ctypes.byref(bad), 0, 4, ctypes.byref(h)) == -1          # invalid argument

@@ -182,8 +182,13 @@ def test_takeoff_rollout_tracks_the_moving_reference(ro, layout):
     ez = _altitude_error(cfg, layout, log, pa, pos)
     assert ez.max() < 0.3, ez.max()
     assert np.abs(log[:, :, 3:6]).max() < 0.15
-    climbing = pa[:, layout.PP_TICK0] < 6000                      # still on the ramp: the robot must actually climb
-    assert (log[-1, climbing, 2] > st[climbing, layout.PS_P + 2] + 0.05).all()
+    # where the tracked (lagged) reference rises during the run, the robot must actually climb with it
+    tick0 = pa[:, layout.PP_TICK0].astype(int)
+    col0 = lambda tk: np.clip(1 + (tk + 1) // cfg.ratio - (cfg.n_ref_cols - 1), 0, len(pos) - 1)
+    rise = pos[col0(tick0 + T), 2] - pos[col0(tick0), 2]
+    climbing = rise > 0.1
+    assert climbing.sum() > 10
+    assert (log[-1, climbing, 2] - st[climbing, layout.PS_P + 2] > 0.5 * rise[climbing]).all()
 
 
 def test_montecarlo_rollout_recovers_from_disturbances(ro, layout):
