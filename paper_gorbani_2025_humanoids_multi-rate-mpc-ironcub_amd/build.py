@@ -17,6 +17,38 @@ HEADERS = ["vsmpc_device.hpp", "vsmpc_launch.hpp", "vsmpc_horizons.def", os.path
            os.path.join("..", "..", "include", "vsmpc_jet.h")]
 
 
+# Horizons (nIter, nIterSmall, controlHorizon) that get a kernel instantiation.  The kernels are straight-line code per
+# horizon (variableSamplingMPC.cpp:24-45 sizes the reference from its XML at run time; here the table is fixed at build
+# time): BASELINE.json's two configurations, plus one odd size that exercises the general paths (controlHorizon odd:
+# joint rows share a tile with throttle rows; three throttle tile rows).  VSMPC_HORIZONS="17,7,12;25,10,18" overrides.
+DEFAULT_HORIZONS = ((17, 7, 12), (34, 14, 24), (21, 9, 15))
+HORIZONS_DEF = os.path.join(CSRC, "vsmpc_horizons.def")
+
+
+def horizons():
+    env = os.environ.get("VSMPC_HORIZONS", "").strip()
+    if not env:
+        return DEFAULT_HORIZONS
+    out = []
+    for item in env.split(";"):
+        n, ns, hc = (int(v) for v in item.split(","))
+        out.append((n, ns, hc))
+    return tuple(out)
+
+
+def write_horizons_def() -> bool:
+    """(Re)writes csrc/vsmpc_horizons.def when the requested table differs; returns True if it changed."""
+    text = ("// Horizons (nIter, nIterSmall, controlHorizon) with a kernel instantiation: one X(...) line each.\n"
+            "// Written by build.py (DEFAULT_HORIZONS or VSMPC_HORIZONS); the first two are BASELINE.json's configurations.\n"
+            + "".join(f"X({n}, {ns}, {hc})\n" for n, ns, hc in horizons()))
+    old = open(HORIZONS_DEF).read() if os.path.exists(HORIZONS_DEF) else None
+    if old != text:
+        with open(HORIZONS_DEF, "w") as f:
+            f.write(text)
+        return True
+    return False
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -33,7 +65,8 @@ def needs_build() -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+    changed = write_horizons_def()
+    if not force and not changed and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]

@@ -385,3 +385,80 @@ def test_horizon2x_blocks_and_batch(mpc2x, ref, synth, layout):
     np.testing.assert_array_equal(x[:, 0:26], big[:, 0:26])
     vmin, vmax = ref.throttle_bounds(rcfg)
     assert x[:, rcfg.off_throttle:].min() >= vmin and x[:, rcfg.off_throttle:].max() <= vmax
+
+
+def test_general_horizon_21_9_15(solver_mod, ref, synth, layout):
+    """A horizon that is neither BASELINE configuration (variableSamplingMPC.cpp:24-45 sizes the reference from the XML;
+    here every horizon of csrc/vsmpc_horizons.def has a kernel): controlHorizon odd, so joint rows share a 16-row tile
+    with throttle rows and the throttle block spans three tile rows (the general corner sweep / primal box QP paths)."""
+    cfg = layout.MPCConfig(n_iter=21, n_iter_small=9, control_horizon=15)
+    rcfg = ref.Config(n_iter=21, n_iter_small=9, control_horizon=15)
+    assert cfg.n_var == 26 * 22 + 8 * 15 + 4 * 7 and cfg.n_con == 26 * 22 + 4 * 13
+    m = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=64)
+    try:
+        assert "21,9,15" in m.kernel_name.replace(" ", "") and m.n_p == 160
+        recs = np.concatenate([synth.make_batch(cfg, 12, workload=w, first_index=5) for w in ("hover", "takeoff", "montecarlo")])
+        A, Bj, Bt, c, dt = m.linearize(recs[:2])
+        np.testing.assert_allclose(dt, ref.dt_schedule(rcfg), rtol=0, atol=1e-17)
+        x, fm, st, it = m.solve(recs)
+        assert (st == layout.STATUS_SOLVED).all()
+        multi = 0
+        for b, rec in enumerate(recs):
+            xr, _, itr, _ = ref.solve_instance(rcfg, rec)
+            assert relerr(x[b], xr) < TOL, (b, relerr(x[b], xr))
+            assert it[b] == itr, (b, it[b], itr)
+            assert relerr(fm[b], ref.first_move_vector(rcfg, xr)) < TOL
+            multi += itr > 1
+        assert multi > 0
+        # saturated throttles on a free tick: the primal box QP with joint rows inside the first corner tile
+        sat = synth.make_batch(cfg, 4, workload="hover", first_index=40)
+        sat[:, layout.IN_HOLD] = 0.0
+        sat[:, layout.IN_XREF + 2::12] += 30.0
+        sat[:, 22] = sat[:, 2] - sat[:, layout.IN_XREF + 2]
+        x, fm, st, it = m.solve(sat)
+        for b, rec in enumerate(sat):
+            xr, _, itr, _ = ref.solve_instance(rcfg, rec)
+            assert st[b] == 1 and relerr(x[b], xr) < TOL and it[b] == itr, (b, relerr(x[b], xr), it[b], itr)
+        assert it.max() >= 3
+    finally:
+        m.close()
+    with pytest.raises(Exception) as e:                      # a horizon without an instantiation is refused, not mis-solved
+        solver_mod.BatchedVSMPC(layout.MPCConfig(n_iter=20, n_iter_small=5, control_horizon=9), device=0, max_batch=4)
+    assert "unsupported" in str(e.value).lower()
+
+
+def test_use_jet_dynamic_false(solver_mod, ref, synth, layout):
+    """useJetDynamic = false (systemDynamicsVSMPC.cpp:384-429: the thrust itself is the input, Bt[12+i][i] = 1, no
+    second-order jet rows): the other branch of P0 against the oracle."""
+    cfg = layout.MPCConfig(use_jet_dynamic=False)
+    rcfg = ref.Config(use_jet_dynamic=False)
+    m = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=32)
+    try:
+        recs = np.concatenate([synth.make_batch(cfg, 8, workload=w) for w in ("hover", "takeoff")])
+        A, Bj, Bt, c, dt = m.linearize(recs)
+        for b, rec in enumerate(recs):
+            Ar, Bjr, Btr, cr = ref.linearize(rcfg, rec)
+            assert relerr(A[b], Ar) < 1e-13 and relerr(Bt[b], Btr) < 1e-13 and relerr(c[b], cr) < 1e-13
+            assert np.array_equal(Bt[b] == 0, Btr == 0) and Bt[b][12, 0] == 1.0
+        x, fm, st, it = m.solve(recs)
+        assert (st == layout.STATUS_SOLVED).all()
+        for b, rec in enumerate(recs):
+            xr, _, itr, _ = ref.solve_instance(rcfg, rec)
+            assert relerr(x[b], xr) < TOL and it[b] == itr, (b, relerr(x[b], xr))
+    finally:
+        m.close()
+
+
+def test_batch_larger_than_handle_is_refused_on_the_device_entry(solver_mod, synth, layout):
+    import torch
+    cfg = layout.paper_config()
+    small = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=4)
+    try:
+        dev = torch.device("cuda:0")
+        d_in = torch.from_numpy(synth.make_batch(cfg, 8)).to(dev)
+        d_st = torch.zeros(8, dtype=torch.int32, device=dev)
+        with pytest.raises(Exception) as e:
+            small.solve_device(d_in, None, None, d_st, None)
+        assert "max_batch" in str(e.value)
+    finally:
+        small.close()
