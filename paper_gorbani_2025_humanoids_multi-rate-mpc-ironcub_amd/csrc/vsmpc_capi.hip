@@ -33,8 +33,8 @@ struct vsmpc_handle {
     hipEvent_t ev0, ev1;
     // host-pointer entry for larger batches: chunks alternate between two streams so that the upload of one chunk, the
     // solve of the previous one and the download of the one before overlap (full overlap needs pinned caller buffers)
-    hipStream_t pipe[2];
-    hipEvent_t pipe_done[2];
+    hipStream_t pipe[4];
+    hipEvent_t pipe_done[4];
     hipEvent_t pipe_start;
     // small batches through the host-pointer entry (the reference's own use: one instance per tick): pinned,
     // device-mapped staging that the kernel reads and writes directly, instead of five small copies
@@ -43,7 +43,8 @@ struct vsmpc_handle {
 };
 
 constexpr int ZC_MAX = 8;  // largest batch served through the mapped staging buffer
-constexpr int PIPE_CHUNK = 1024;  // instances per chunk of the pipelined host-pointer entry
+constexpr int PIPE_CHUNK = 512;   // instances per chunk of the pipelined host-pointer entry (one round of two workgroups per CU)
+constexpr int PIPE_STREAMS = 4;
 
 // resident closed-loop state of a batch (uses the handle's record / first-move / status buffers as its per-tick scratch)
 struct vsmpc_rollout {
@@ -173,7 +174,7 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     if (e == hipSuccess) e = hipMalloc(&h->d_kin, B * VSMPC_KIN_SIZE * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->d_kout, B * VSMPC_KIN_OUT * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&h->d_stamps, B * 16 * sizeof(unsigned long long));
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    for (int i = 0; i < PIPE_STREAMS && e == hipSuccess; ++i) {
         e = hipStreamCreateWithFlags(&h->pipe[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pipe_done[i], hipEventDisableTiming);
     }
@@ -206,7 +207,7 @@ void vsmpc_destroy(vsmpc_handle* h) {
     if (h->d_kin) (void)hipFree(h->d_kin);
     if (h->d_kout) (void)hipFree(h->d_kout);
     if (h->d_stamps) (void)hipFree(h->d_stamps);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PIPE_STREAMS; ++i) {
         if (h->pipe[i]) (void)hipStreamDestroy(h->pipe[i]);
         if (h->pipe_done[i]) (void)hipEventDestroy(h->pipe_done[i]);
     }
@@ -264,16 +265,17 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         if (iters) memcpy(iters, hit, B * sizeof(int));
         return VSMPC_OK;
     }
-    // chunks of PIPE_CHUNK instances alternate between the handle's two streams: upload(k+1) | solve(k) | download(k-1)
+    // chunks of PIPE_CHUNK instances rotate over the handle's streams: upload(k+1) | solve(k) | download(k-1)
     // overlap when the caller's buffers are pinned (hipHostMalloc / vsmpc_alloc_host); with pageable buffers the
     // runtime stages the copies itself and the chunks still overlap with the kernels
     HIP_TRY(hipEventRecord(h->pipe_start, s));                 // work queued on the caller's stream comes first
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamWaitEvent(h->pipe[i], h->pipe_start, 0));
+    const int nstreams = std::min(PIPE_STREAMS, (batch + PIPE_CHUNK - 1) / PIPE_CHUNK);
+    for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamWaitEvent(h->pipe[i], h->pipe_start, 0));
     int k = 0;
     for (int first = 0; first < batch; first += PIPE_CHUNK, ++k) {
         const int n = std::min(PIPE_CHUNK, batch - first);
         const size_t o = size_t(first), N = size_t(n);
-        hipStream_t ps = h->pipe[k & 1];
+        hipStream_t ps = h->pipe[k % nstreams];
         HIP_TRY(hipMemcpyAsync(h->d_in + o * h->n_in, in + o * h->n_in, N * h->n_in * sizeof(double), hipMemcpyHostToDevice, ps));
         HIP_TRY(launch_solve(h->variant, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
                              h->d_fm + o * VSMPC_FM_SIZE, h->d_status + o, h->d_iters + o, nullptr, nullptr, nullptr, ps));
@@ -284,12 +286,11 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         HIP_TRY(hipMemcpyAsync(status + o, h->d_status + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
         if (iters) HIP_TRY(hipMemcpyAsync(iters + o, h->d_iters + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < nstreams; ++i) {
         HIP_TRY(hipEventRecord(h->pipe_done[i], h->pipe[i]));
-        HIP_TRY(hipStreamWaitEvent(s, h->pipe_done[i], 0));   // the caller's stream continues after both
+        HIP_TRY(hipStreamWaitEvent(s, h->pipe_done[i], 0));   // the caller's stream continues after all of them
     }
-    HIP_TRY(hipStreamSynchronize(h->pipe[0]));
-    HIP_TRY(hipStreamSynchronize(h->pipe[1]));
+    for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(h->pipe[i]));
     return VSMPC_OK;
 }
 

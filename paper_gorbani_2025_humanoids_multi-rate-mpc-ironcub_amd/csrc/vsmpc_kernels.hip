@@ -288,13 +288,13 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 //     a load issued behind instruction e is there for instruction e + 3.  `ha`/`hb` carry the first SYRK_DIST operand
 //     pairs of the slot in and those of the NEXT slot (slot q - 1) out.
 // ------------------------------------------------------------------------------------------------
-constexpr int SYRK_DIST = 3;
+constexpr int SYRK_DIST = 2;
 
 template <class D, int NKS>
 VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __restrict__ pb, double (&ha)[SYRK_DIST],
                       double (&hb)[SYRK_DIST], const double* __restrict__ pan, const double* __restrict__ pbn) {
-    static_assert(NKS > SYRK_DIST, "pipeline depth");
-    double av[NKS + SYRK_DIST], bv[NKS + SYRK_DIST];
+    static_assert(NKS >= 2 * SYRK_DIST - 1, "pipeline depth");
+    double av[NKS], bv[NKS], na[SYRK_DIST], nb[SYRK_DIST];
 #pragma unroll
     for (int ks = 0; ks < SYRK_DIST; ++ks) { av[ks] = ha[ks]; bv[ks] = hb[ks]; }
 #pragma unroll
@@ -305,14 +305,28 @@ VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __re
         if (n < NKS) {
             av[n] = pa[n * 4 * D::YS];
             bv[n] = pb[n * 4 * D::YS];
-        } else {  // head of the next slot
-            av[n] = pan[(n - NKS) * 4 * D::YS];
-            bv[n] = pbn[(n - NKS) * 4 * D::YS];
+        }
+        // the head of the NEXT slot is requested behind the FIRST instructions of this chain, not the last ones: by the
+        // control-flow join that follows the chain every load has long returned (the compiler drains the LDS counter at
+        // a join: it cannot count outstanding loads across predecessors)
+        if (ks < SYRK_DIST) {
+            na[ks] = pan[ks * 4 * D::YS];
+            nb[ks] = pbn[ks * 4 * D::YS];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = av[NKS + ks]; hb[ks] = bv[NKS + ks]; }
+    for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = na[ks]; hb[ks] = nb[ks]; }
+}
+
+// all TPW slots of a wavefront in a row, no branch in between (passes in which every tile is active)
+template <class D, int NKS, int TPW, class SA, class SB>
+VS_DEV void syrk_all(d4 (&acc)[TPW], double (&ha)[SYRK_DIST], double (&hb)[SYRK_DIST], const SA& slot_a, const SB& slot_b) {
+#pragma unroll
+    for (int q = TPW - 1; q >= 0; --q) {
+        const int qn = q > 0 ? q - 1 : 0;
+        syrk_slot<D, NKS>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+    }
 }
 
 // entry into the slot sequence at slot nact - 1 (fall-through switch; see syrk_slot)
@@ -385,8 +399,7 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
     }
     double dmin = 1.0;     // all pivots positive <=> min(pivots) > 0; a NaN pivot (fmin skips it) makes every later
                            // pivot and the last reciprocal square root NaN, which is checked at the end
-    const bool keeps_invd = lane == 0 && (!SPLIT || w == 0);   // 1/L_jj goes to LDS as it is formed (no register array)
-    double inv_last = 1.0;
+    double inv_mine = 1.0, inv_last = 1.0;   // lane j keeps 1/L_jj (a select per pivot, no branch on the pivot chain)
     // software-pipelined pivots: the next pivot is complete as soon as the first column of this pivot's update is
     // done, so its reciprocal square root (a ~75-cycle dependent chain) is issued there and overlaps the rest of the
     // update instead of following it
@@ -395,7 +408,7 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll
     for (int j = 0; j < NPIV; ++j) {
         dmin = fmin(dmin, d);
-        if (keeps_invd) sInvD[16 * p + j] = inv;
+        inv_mine = lane == j ? inv : inv_mine;
         inv_last = inv;
         double l[NSLOT];
 #pragma unroll
@@ -430,6 +443,7 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #pragma unroll
             for (int c = 0; c < 16; ++c) T[s][c] = a[s][c];
         }
+    if (lane < NPIV && (!SPLIT || w == 0)) sInvD[16 * p + lane] = inv_mine;
     return !(dmin > 0.0) || !(inv_last == inv_last);
 }
 
@@ -1310,7 +1324,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
 
         // coefficient rows of this half: wave-uniform LDS broadcasts, re-read at the top of every pass so that they are
         // dead during the matrix-core section (the accumulator tiles stay in registers for the whole of P1..P5)
-        double M1[9], Sk[9], Ce[3];
+        double M1[9], Sk[9], Ce[3], sqx[3], sqh[3], sqe[3];
         auto load_coeffs = [&]() {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -1320,11 +1334,11 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
                 }
                 Ce[r] = sC[er0 + r];
+                sqx[r] = sCfg[CFG_SQ + yx0 + r];
+                sqh[r] = sCfg[CFG_SQ + yh0 + r];
+                sqe[r] = sCfg[CFG_SQ + ye0 + r];
             }
         };
-        double sqx[3], sqh[3], sqe[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { sqx[r] = sCfg[CFG_SQ + yx0 + r]; sqh[r] = sCfg[CFG_SQ + yh0 + r]; sqe[r] = sCfg[CFG_SQ + ye0 + r]; }
         // MFMA operand addresses: lane l reads Y[4 ks + (l >> 4)][16 tile + (l & 15)]; the k-step enters as an
         // immediate offset of ds_read_b64
         const int ylane = (lane >> 4) * D::YS + (lane & 15);
@@ -1335,7 +1349,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // Y is single-buffered (two barriers per pass): the second buffer is what kept a second workgroup off the CU,
         // and a co-resident workgroup fills the recursion's bubbles far better than the look-ahead did.
         int col[CPT], kind[CPT], blk[CPT];   // kind: 0 joint column, 1 throttle column, 2 affine column, 3 pad
-        double aff[CPT], xs[CPT][3], hs[CPT][3], es[CPT][3], bh[CPT][3], amt[CPT][3];
+        double aff[CPT], xs[CPT][3], hs[CPT][3], es[CPT][3], bha[CPT][3];
         const double* jetT[CPT];
         const double* gaT = sGA + half * 3 * D::N;
 #pragma unroll
@@ -1360,8 +1374,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 xs[cc][r] = aff_col ? x0 : 0.0;
                 hs[cc][r] = aff_col ? h0 : 0.0;
                 es[cc][r] = aff_col ? e0 : 0.0;
-                bh[cc][r] = jnt_col ? bj : (aff_col ? ch : 0.0);
-                amt[cc][r] = thr_col ? at : 0.0;  // thrust map column of the one jet this throttle column drives
+                // one input vector per column: joint column -> Bj column (scaled by the block activity), affine column -> c
+                // (always on), throttle column -> thrust map column of the one jet it drives (scaled by that jet's T_k)
+                bha[cc][r] = jnt_col ? bj : (aff_col ? ch : (thr_col ? at : 0.0));
             }
             // this column's thrust trajectory: a throttle column's own jet, the zero row otherwise (the affine column's
             // four jets enter through sGA)
@@ -1402,16 +1417,15 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     const double tk = jetT[cc][k];
                     const bool actJ = (kind[cc] == 0 && joint_block_of_stage<D>(k) == blk[cc]) || kind[cc] == 2;
                     // input activity as a 0/1 factor inside the multiply-adds (a 64-bit select costs two instructions)
-                    const double mJ = actJ ? 1.0 : 0.0;
+                    const double scale = kind[cc] == 1 ? tk : (actJ ? 1.0 : 0.0);
                     double dx[3], dh[3], de[3];
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        double a0 = M1[3 * r] * hs[cc][0], a1 = mJ * bh[cc][r], a2 = aff[cc] * ga[r];
+                        double a0 = M1[3 * r] * hs[cc][0], a1 = scale * bha[cc][r], a2 = aff[cc] * ga[r];
 #pragma unroll
                         for (int c = 1; c < 3; ++c) a0 = fma(M1[3 * r + c], hs[cc][c], a0);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) a1 = fma(Sk[3 * r + c], hs[cc][c], a1);
-                        a2 = fma(amt[cc][r], tk, a2);
                         dx[r] = a0;
                         dh[r] = a1 + a2;
                         de[r] = fma(aff[cc], Ce[r], xs[cc][r]);
@@ -1445,8 +1459,12 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     double ha[SYRK_DIST], hb[SYRK_DIST];
 #pragma unroll
                     for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = pa0[ks * 4 * D::YS]; hb[ks] = pb0[ks * 4 * D::YS]; }
-                    if (nnodes == 2) syrk_enter<D, 9, TPW>(nact, acc, ha, hb, slot_a, slot_b);
-                    else syrk_enter<D, 5, TPW>(nact, acc, ha, hb, slot_a, slot_b);
+                    if (nnodes == 2) {
+                        if (nact == TPW) syrk_all<D, 9, TPW>(acc, ha, hb, slot_a, slot_b);   // straight-line: no joins
+                        else syrk_enter<D, 9, TPW>(nact, acc, ha, hb, slot_a, slot_b);
+                    } else {
+                        syrk_enter<D, 5, TPW>(nact, acc, ha, hb, slot_a, slot_b);
+                    }
                 }
             } else {
                 // long horizons (30 slots, one workgroup per CU, 512 registers): one scalar branch per slot in ascending

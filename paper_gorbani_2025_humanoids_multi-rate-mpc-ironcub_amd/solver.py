@@ -17,6 +17,7 @@ import numpy as np
 
 from . import _lib
 from . import layout as L
+from .jet_model import JetModel
 
 
 def _ptr(a):
@@ -153,7 +154,10 @@ class VariableSamplingMPC:
 
     The reference's update(QPInput) pulls the per-tick quantities out of a live iDynTree-backed Robot;
     that kinematics provider is outside the path, so `update` takes the already
-    extracted input record (layout.IN_*), which is exactly what the device path consumes.
+    extracted input record (layout.IN_*), which is exactly what the device path consumes.  This class carries the
+    joint accumulator and "consume only if Solved"; the tick-state fields of the record (hold flag, unwrapped RPY,
+    reference window, alpha cursor) are the caller's here -- `reference_api.VariableSamplingMPC` is the mirror that
+    takes a QPInput and runs the reference's whole tick state machine itself.
     """
 
     N_ROBOT_JOINTS = 23  # MPCPyBindings.cpp:43 hard-codes 23 joints
@@ -172,6 +176,9 @@ class VariableSamplingMPC:
         self._thrustReference = np.zeros(4)
         self._thrustDotReference = np.zeros(4)
         self._throttleReference = np.zeros(4)       # stored as warped v (variableSamplingMPC.cpp:100)
+        # what getThrottleReference returns before the first Solved tick: destandardizeThrottle_u2T of the zero-initialised
+        # warped throttle, as the reference's getter computes it from its stored member (variableSamplingMPC.cpp:138-151)
+        self._throttlePercent = np.array([JetModel().destandardizeThrottle_u2T(0.0)] * 4)
         self._deltaJoints = np.zeros(8)
         self._QPSolution = np.zeros(cfg.n_var)
         self._finalState = np.zeros(26)
