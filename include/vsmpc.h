@@ -256,6 +256,14 @@ int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
 void* vsmpc_alloc_host(size_t bytes);
 void vsmpc_free_host(void* p);
 
+/* The solve kernel has two forms for horizons whose condensed dimension is <= 128 (the paper's): the THROUGHPUT form
+ * (two instances share a compute unit and fill each other's stalls) and the LATENCY form (one instance per compute unit,
+ * eight wavefronts, the sensitivity recursion of the next pass runs beside the matrix-core work of the current one).
+ * Default (form 0): latency form when the batch leaves no compute unit with two instances, throughput form otherwise.
+ * form 1 pins the throughput form, form 2 the latency form (process-wide; measurements and tests; results of the two
+ * forms are bit-identical).  Returns the previous setting, or VSMPC_ERR_INVALID_ARG. */
+int vsmpc_set_kernel_form(int form);
+
 const char* vsmpc_strerror(int code);
 const char* vsmpc_kernel_name(const vsmpc_handle* h);
 

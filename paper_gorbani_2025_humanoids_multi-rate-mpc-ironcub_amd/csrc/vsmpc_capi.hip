@@ -649,6 +649,11 @@ int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records) {
     return VSMPC_OK;
 }
 
+int vsmpc_set_kernel_form(int form) {
+    if (form < 0 || form > 2) return VSMPC_ERR_INVALID_ARG;
+    return set_kernel_form(form);
+}
+
 void* vsmpc_alloc_host(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

@@ -32,6 +32,7 @@
 // it (shared FP64 datapath); one FP64 FMA costs ~5.7 cycles for a lone wavefront, v_readlane pair + FMA
 // ~21.6.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
 // streams carry nothing but operand loads.
+#include <cstdlib>
 #include <type_traits>
 
 #include "vsmpc_device.hpp"
@@ -120,6 +121,10 @@ struct Smem {
     static constexpr int total = oR + (sizeY > sizeM ? sizeY : sizeM);
     static constexpr size_t bytes = size_t(total) * sizeof(double);
     static_assert(bytes <= 160 * 1024, "LDS budget of one CU");
+    // latency form of the kernel (one workgroup per CU, see solve_kernel): a second Y buffer right behind the first
+    static constexpr int total_lat = oR + (2 * sizeY > sizeM ? 2 * sizeY : sizeM);
+    static constexpr size_t bytes_lat = size_t(total_lat) * sizeof(double);
+    static_assert(D::WG_PER_CU < 2 || bytes_lat <= 160 * 1024, "LDS budget of one CU");
 };
 
 // tile (i, j), j <= i, of the factor in LDS: panel columns left of the throttle corner live in a ring of two
@@ -1163,8 +1168,13 @@ VS_DEV const SolveArgs* late_args() {
 
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
 // `stamps` (its own buffer, never read by the kernel).  The shipped instantiation has STAMPS = false.
-template <class D, bool STAMPS>
-__global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
+// LAT (latency form, batches that leave CUs to spare): eight wavefronts, one workgroup per CU.  Wavefronts 4..7 run the
+// sensitivity recursion of pass m + 1 into a second Y buffer while wavefronts 0..3 run the SYRK of pass m (one barrier
+// per pass), and end after the last pass; a barrier only counts the wavefronts that are still alive, so P2..P6 are the
+// four-wavefront code unchanged.  The throughput form (two workgroups per CU) hides the recursion behind the
+// co-resident workgroup instead and needs the LDS for it.
+template <class D, bool STAMPS, bool LAT = false>
+__global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* xout_, double* fmout_, int* status_out_,
                                                          int* iters_out_, double* dbgM_, double* dbgL_,
                                                          unsigned long long* stamps_) {
@@ -1255,7 +1265,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             sCfg[CFG_WREG] = cfg.w_reg; sCfg[CFG_WTHR] = cfg.w_thr; sCfg[CFG_WINIT] = cfg.w_init;
             sCfg[CFG_VMIN] = cfg.vmin; sCfg[CFG_VMAX] = cfg.vmax;
         }
-        for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
+        if (tid < D::BLOCK)   // (the recursion wavefronts of the latency form take no part in P0)
+            for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
         if (tid < D::NIN / 2) sIn2[tid] = rec;
     }
     __syncthreads();
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         for (int k = lane; k < D::N; k += 64) sJetT[ZROW * D::N + k] = 0.0;
     }
     __syncthreads();   // ends P0 and the jet trajectories
-    for (int e = tid; e < 6 * D::N; e += D::BLOCK) {
+    for (int e = tid; e < 6 * D::N && tid < D::BLOCK; e += D::BLOCK) {
         const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3, row = (h ? 9 : 3) + r;
         double g = 0.0;
 #pragma unroll
@@ -1318,7 +1329,12 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // P1b: thread (half, c): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy) of the
         // condensed columns c, c + 128, ... (CPT of them; one at the paper horizon).  Same code, different coefficient rows.
         constexpr int CPT = D::CPT;
-        const int half = wave / (D::NWAVES / 2);  // scalar
+        // latency form: wavefronts NWAVES.. run the recursion (rec_wave), wavefronts 0..NWAVES-1 the SYRK (mm_wave);
+        // throughput form: every wavefront does both, one after the other
+        const int pw = LAT ? (wave & (D::NWAVES - 1)) : wave;
+        const int ptid = LAT ? (tid & (D::BLOCK - 1)) : tid;
+        const bool rec_wave = !LAT || wave >= D::NWAVES, mm_wave = !LAT || wave < D::NWAVES;
+        const int half = pw / (D::NWAVES / 2);  // scalar
         const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
         const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
 
@@ -1354,7 +1370,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         const double* gaT = sGA + half * 3 * D::N;
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) {
-            const int c = cc * D::PCOLS + tid % D::PCOLS;
+            const int c = cc * D::PCOLS + ptid % D::PCOLS;
             int comp = 0;
             col[cc] = c;
             kind[cc] = 3;
@@ -1385,8 +1401,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // wave-uniform tile coordinates of the slots, packed two slots per scalar register (see TilePack)
         unsigned tpk[TilePack<D>::NWORDS];
 #pragma unroll
-        for (int k = 0; k < TilePack<D>::NWORDS; ++k) tpk[k] = kTilePack<D>.w[wave][k];
-        const double* ybase = sY + ylane;
+        for (int k = 0; k < TilePack<D>::NWORDS; ++k) tpk[k] = kTilePack<D>.w[pw][k];
+        const double* ybase = sY + ylane;   // + the buffer of the pass (latency form: two Y buffers)
         auto slot_a = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1))) & 0xffu); };
         auto slot_b = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu); };
 #pragma unroll 1
@@ -1395,10 +1411,16 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             VS_TIC();
             // scalar table lookups of this pass's SYRK, requested before the recursion: active slots of this wavefront
             // (a prefix) and the tile of the first slot to run
-            const int nact = kNactTab<D>.n[m][wave];
-            const int t0 = (nact > 0 ? nact - 1 : 0) * D::NWAVES + wave;
+            const int nact = kNactTab<D>.n[m][pw];
+            const int t0 = (nact > 0 ? nact - 1 : 0) * D::NWAVES + pw;
+            double* sYm = sY;
+            if constexpr (LAT) {
+                sYm = sY + (m & 1) * S::sizeY;
+                ybase = sYm + ylane;
+            }
             const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
             const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
+            if (rec_wave) {
             load_coeffs();
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -1434,7 +1456,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     for (int r = 0; r < 3; ++r) { xs[cc][r] += dt * dx[r]; hs[cc][r] += dt * dh[r]; es[cc][r] += dt * de[r]; }
                     // Y rows of this node: sqrt(Q) (S_k - xref_k on the affine column); column map costsVSMPC.cpp:191-200
                     if (CPT == 1 || col[cc] < D::NP) {
-                        double* Yn = sY + 18 * par * D::YS + col[cc];
+                        double* Yn = sYm + 18 * par * D::YS + col[cc];
 #pragma unroll
                         for (int r = 0; r < 3; ++r) {
                             const double vx = fma(-aff[cc], xrx[r], xs[cc][r]);  // aff = 1 on the affine column, else 0
@@ -1447,10 +1469,12 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 }
             }
             if (nnodes == 1)  // rows 18,19 of the last, single-node pass (k-step 4 reads rows 16..19)
-                for (int i = tid; i < 2 * D::YS; i += D::BLOCK) sY[18 * D::YS + i] = 0.0;
+                for (int i = ptid; i < 2 * D::YS; i += D::BLOCK) sYm[18 * D::YS + i] = 0.0;
+            }
             VS_TOC(0);
             __syncthreads();
             VS_TOC(1);
+            if (mm_wave) {
             // C += Y^T Y over this pass: D = A*B, A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n].
             // Columns that are not active yet are exactly zero, so skipping a tile is only an optimisation.
             if constexpr (TPW <= 12) {
@@ -1490,10 +1514,14 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     }
                 }
             }
+            }
             VS_TOC(2);
-            __syncthreads();  // single Y buffer: the next pass overwrites it
+            if constexpr (!LAT) __syncthreads();  // single Y buffer: the next pass overwrites it
         }
         VS_TIC();
+    }
+    if constexpr (LAT) {
+        if (wave >= D::NWAVES) return;   // the recursion wavefronts are done; later barriers count the live wavefronts only
     }
     VS_STAMP(2);
     VS_REFRESH_IDS();
@@ -1970,25 +1998,71 @@ hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipS
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_DEVICES = 64;
 
-template <class D, bool STAMPS>
-static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+// compute units of a device (cached): a batch that leaves none of them with two instances runs the latency form
+static hipError_t device_cus(int dev, int* cus) {
+    static int cached[MAX_DEVICES] = {};
+    if (cached[dev] == 0) {
+        int n = 0;
+        hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cached[dev] = n > 0 ? n : 1;
+    }
+    *cus = cached[dev];
+    return hipSuccess;
+}
+
+// kernel form: 0 by batch size, 1 throughput, 2 latency (vsmpc_set_kernel_form; VSMPC_FORM=throughput|latency sets
+// the initial value for measurements of unmodified programs)
+static int g_form = -1;
+static int forced_form() {
+    if (g_form < 0) {
+        const char* v = getenv("VSMPC_FORM");
+        g_form = (v != nullptr && v[0] == 't') ? 1 : (v != nullptr && v[0] == 'l') ? 2 : 0;
+    }
+    return g_form;
+}
+int set_kernel_form(int form) {
+    const int prev = forced_form();
+    g_form = form;
+    return prev;
+}
+
+template <class D, bool STAMPS, bool LAT>
+static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
                                  unsigned long long* stamps, hipStream_t stream) {
     // the dynamic-LDS limit is a per-device function attribute: one process may drive several devices
     static bool attr_set[MAX_DEVICES] = {};
+    constexpr size_t lds = LAT ? Smem<D>::bytes_lat : Smem<D>::bytes;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS, LAT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((solve_kernel<D, STAMPS, LAT>), dim3(batch), dim3(LAT ? 2 * D::BLOCK : D::BLOCK), lds, stream,
+                       cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
+    return hipGetLastError();
+}
+
+template <class D, bool STAMPS>
+static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+                                 int* d_status, int* d_iters, double* dbgM, double* dbgL,
+                                 unsigned long long* stamps, hipStream_t stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, int(Smem<D>::bytes));
-        if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+    if constexpr (D::WG_PER_CU >= 2) {   // horizons whose wavefronts fit 256 registers: two forms
+        int cus = 0;
+        if ((e = device_cus(dev, &cus)) != hipSuccess) return e;
+        const int form = forced_form();
+        if (form == 2 || (form == 0 && batch <= cus))
+            return launch_solve_f<D, STAMPS, true>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
+                                                   stamps, stream);
     }
-    hipLaunchKernelGGL((solve_kernel<D, STAMPS>), dim3(batch), dim3(D::BLOCK), Smem<D>::bytes, stream, cfg, d_in, batch,
-                       d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
-    return hipGetLastError();
+    return launch_solve_f<D, STAMPS, false>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
+                                            stream);
 }
 
 template <class D>

@@ -24,6 +24,18 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+KERNEL_FORM_AUTO, KERNEL_FORM_THROUGHPUT, KERNEL_FORM_LATENCY = 0, 1, 2
+
+
+def set_kernel_form(form: int) -> int:
+    """vsmpc_set_kernel_form (include/vsmpc.h): pins the throughput / latency form of the solve kernel process-wide;
+    returns the previous setting."""
+    prev = _lib.load().vsmpc_set_kernel_form(int(form))
+    if prev < 0:
+        raise ValueError(f"kernel form {form}")
+    return prev
+
+
 class BatchedVSMPC:
     """`max_batch` independent MPC instances on one GPU (one workgroup per instance)."""
 

@@ -223,6 +223,29 @@ def test_device_entry_matches_host_entry(mpc, synth, layout):
     assert (d_st.cpu().numpy() == layout.STATUS_SOLVED).all()
 
 
+def test_latency_and_throughput_forms_are_bit_identical(mpc, solver_mod, synth, layout):
+    """The two forms of the solve kernel (include/vsmpc.h, vsmpc_set_kernel_form) run the same arithmetic in the same
+    order: outputs, statuses, iteration counts, condensed Hessian and factor must be equal bit for bit."""
+    cfg = layout.paper_config()
+    recs = np.concatenate([synth.make_batch(cfg, 48, workload="takeoff"), synth.make_batch(cfg, 48, workload="montecarlo")])
+    prev = solver_mod.set_kernel_form(solver_mod.KERNEL_FORM_THROUGHPUT)
+    try:
+        a = mpc.solve(recs)
+        Ma, La = mpc.debug_condensed(recs[5])[:2]
+        assert solver_mod.set_kernel_form(solver_mod.KERNEL_FORM_LATENCY) == solver_mod.KERNEL_FORM_THROUGHPUT
+        b = mpc.solve(recs)
+        Mb, Lb = mpc.debug_condensed(recs[5])[:2]
+    finally:
+        solver_mod.set_kernel_form(prev)
+    assert (a[2] == layout.STATUS_SOLVED).all()
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(Ma, Mb)
+    np.testing.assert_array_equal(La, Lb)
+    with pytest.raises(ValueError):
+        solver_mod.set_kernel_form(7)
+
+
 def test_edge_cases(mpc, solver_mod, synth, layout, ref):
     cfg, rcfg = layout.paper_config(), ref.paper_config()
     # empty batch
