@@ -50,6 +50,24 @@ __device__ constexpr NactTab<D> kNactTab{};
 template <class D>
 __device__ constexpr TilePack<D> kTilePack{};
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = I0 .. N-1
+template <int I, int N, class F>
+VS_DEV void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// active accumulator slots of SYRK pass m, maximum over the wavefronts (see NactTab)
+template <class D>
+constexpr int nact_max(int m) {
+    constexpr NactTab<D> t{};
+    int n = 0;
+    for (int w = 0; w < D::NWAVES; ++w) n = t.n[m][w] > n ? t.n[m][w] : n;
+    return n;
+}
+
 VS_DEV double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
@@ -293,9 +311,29 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 //     a load issued behind instruction e is there for instruction e + 3.  `ha`/`hb` carry the first SYRK_DIST operand
 //     pairs of the slot in and those of the NEXT slot (slot q - 1) out.
 // ------------------------------------------------------------------------------------------------
-constexpr int SYRK_DIST = 2;
+#ifndef VS_SYRK_DIST
+#define VS_SYRK_DIST 2
+#endif
+#ifndef VS_SYRK_TIED
+#define VS_SYRK_TIED 0
+#endif
+#ifndef VS_SYRK_UNROLL
+#define VS_SYRK_UNROLL 1
+#endif
+#ifndef VS_SYRK_ALL
+#define VS_SYRK_ALL 0
+#endif
+constexpr int SYRK_DIST = VS_SYRK_DIST;
 
-template <class D, int NKS>
+// TIED: the matrix instruction is written as inline assembly whose accumulator is a read-write operand, i.e. the result
+// lands in the registers the tile already occupies.  With the builtin the register allocator is free to put the result
+// of a chain's first instruction into fresh registers, and at the control-flow joins around the chains it then moves
+// whole tiles back (measured: ~1.1k cycles per pass, whatever the number of chains).  The compiler does not know that the
+// statement is a matrix instruction, so the software wait states between it and a vector instruction that touches the
+// tile are placed by hand: 18 behind the last instruction of a chain (CDNA3 ISA 4.5: DGEMM 16x16x4 result -> VALU
+// read/write), which cost nothing -- the matrix pipe is busy for 64 cycles with that instruction anyway -- and 2 in
+// front of the first one (vector write -> matrix read).  Within a chain the accumulator forwards back to back.
+template <class D, int NKS, bool TIED = false>
 VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __restrict__ pb, double (&ha)[SYRK_DIST],
                       double (&hb)[SYRK_DIST], const double* __restrict__ pan, const double* __restrict__ pbn) {
     static_assert(NKS >= 2 * SYRK_DIST - 1, "pipeline depth");
@@ -304,7 +342,17 @@ VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __re
     for (int ks = 0; ks < SYRK_DIST; ++ks) { av[ks] = ha[ks]; bv[ks] = hb[ks]; }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+        if constexpr (TIED) {
+            if (ks == 0)
+                asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(av[ks]), "v"(bv[ks]));
+            else if (ks == NKS - 1)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 1"
+                             : "+v"(acc) : "v"(av[ks]), "v"(bv[ks]));
+            else
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(av[ks]), "v"(bv[ks]));
+        } else {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int n = ks + SYRK_DIST;
         if (n < NKS) {
@@ -330,47 +378,21 @@ VS_DEV void syrk_all(d4 (&acc)[TPW], double (&ha)[SYRK_DIST], double (&hb)[SYRK_
 #pragma unroll
     for (int q = TPW - 1; q >= 0; --q) {
         const int qn = q > 0 ? q - 1 : 0;
-        syrk_slot<D, NKS>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+        syrk_slot<D, NKS, VS_SYRK_TIED>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
     }
 }
 
-// entry into the slot sequence at slot nact - 1 (fall-through switch; see syrk_slot)
+// the active slots nact - 1, ..., 0 of a wavefront, one scalar branch per slot.  Every chain updates its tile in place
+// (TIED), so the joins behind the branches carry no copies.
 template <class D, int NKS, int TPW, class SA, class SB>
 VS_DEV void syrk_enter(int nact, d4 (&acc)[TPW], double (&ha)[SYRK_DIST], double (&hb)[SYRK_DIST], const SA& slot_a,
                        const SB& slot_b) {
-    static_assert(TPW <= 30, "extend the switch");
-    switch (nact) {
-        case 30: if constexpr (TPW >= 30) syrk_slot<D, NKS>(acc[29], slot_a(29), slot_b(29), ha, hb, slot_a(28), slot_b(28)); [[fallthrough]];
-        case 29: if constexpr (TPW >= 29) syrk_slot<D, NKS>(acc[28], slot_a(28), slot_b(28), ha, hb, slot_a(27), slot_b(27)); [[fallthrough]];
-        case 28: if constexpr (TPW >= 28) syrk_slot<D, NKS>(acc[27], slot_a(27), slot_b(27), ha, hb, slot_a(26), slot_b(26)); [[fallthrough]];
-        case 27: if constexpr (TPW >= 27) syrk_slot<D, NKS>(acc[26], slot_a(26), slot_b(26), ha, hb, slot_a(25), slot_b(25)); [[fallthrough]];
-        case 26: if constexpr (TPW >= 26) syrk_slot<D, NKS>(acc[25], slot_a(25), slot_b(25), ha, hb, slot_a(24), slot_b(24)); [[fallthrough]];
-        case 25: if constexpr (TPW >= 25) syrk_slot<D, NKS>(acc[24], slot_a(24), slot_b(24), ha, hb, slot_a(23), slot_b(23)); [[fallthrough]];
-        case 24: if constexpr (TPW >= 24) syrk_slot<D, NKS>(acc[23], slot_a(23), slot_b(23), ha, hb, slot_a(22), slot_b(22)); [[fallthrough]];
-        case 23: if constexpr (TPW >= 23) syrk_slot<D, NKS>(acc[22], slot_a(22), slot_b(22), ha, hb, slot_a(21), slot_b(21)); [[fallthrough]];
-        case 22: if constexpr (TPW >= 22) syrk_slot<D, NKS>(acc[21], slot_a(21), slot_b(21), ha, hb, slot_a(20), slot_b(20)); [[fallthrough]];
-        case 21: if constexpr (TPW >= 21) syrk_slot<D, NKS>(acc[20], slot_a(20), slot_b(20), ha, hb, slot_a(19), slot_b(19)); [[fallthrough]];
-        case 20: if constexpr (TPW >= 20) syrk_slot<D, NKS>(acc[19], slot_a(19), slot_b(19), ha, hb, slot_a(18), slot_b(18)); [[fallthrough]];
-        case 19: if constexpr (TPW >= 19) syrk_slot<D, NKS>(acc[18], slot_a(18), slot_b(18), ha, hb, slot_a(17), slot_b(17)); [[fallthrough]];
-        case 18: if constexpr (TPW >= 18) syrk_slot<D, NKS>(acc[17], slot_a(17), slot_b(17), ha, hb, slot_a(16), slot_b(16)); [[fallthrough]];
-        case 17: if constexpr (TPW >= 17) syrk_slot<D, NKS>(acc[16], slot_a(16), slot_b(16), ha, hb, slot_a(15), slot_b(15)); [[fallthrough]];
-        case 16: if constexpr (TPW >= 16) syrk_slot<D, NKS>(acc[15], slot_a(15), slot_b(15), ha, hb, slot_a(14), slot_b(14)); [[fallthrough]];
-        case 15: if constexpr (TPW >= 15) syrk_slot<D, NKS>(acc[14], slot_a(14), slot_b(14), ha, hb, slot_a(13), slot_b(13)); [[fallthrough]];
-        case 14: if constexpr (TPW >= 14) syrk_slot<D, NKS>(acc[13], slot_a(13), slot_b(13), ha, hb, slot_a(12), slot_b(12)); [[fallthrough]];
-        case 13: if constexpr (TPW >= 13) syrk_slot<D, NKS>(acc[12], slot_a(12), slot_b(12), ha, hb, slot_a(11), slot_b(11)); [[fallthrough]];
-        case 12: if constexpr (TPW >= 12) syrk_slot<D, NKS>(acc[11], slot_a(11), slot_b(11), ha, hb, slot_a(10), slot_b(10)); [[fallthrough]];
-        case 11: if constexpr (TPW >= 11) syrk_slot<D, NKS>(acc[10], slot_a(10), slot_b(10), ha, hb, slot_a(9), slot_b(9)); [[fallthrough]];
-        case 10: if constexpr (TPW >= 10) syrk_slot<D, NKS>(acc[9], slot_a(9), slot_b(9), ha, hb, slot_a(8), slot_b(8)); [[fallthrough]];
-        case 9: if constexpr (TPW >= 9) syrk_slot<D, NKS>(acc[8], slot_a(8), slot_b(8), ha, hb, slot_a(7), slot_b(7)); [[fallthrough]];
-        case 8: if constexpr (TPW >= 8) syrk_slot<D, NKS>(acc[7], slot_a(7), slot_b(7), ha, hb, slot_a(6), slot_b(6)); [[fallthrough]];
-        case 7: if constexpr (TPW >= 7) syrk_slot<D, NKS>(acc[6], slot_a(6), slot_b(6), ha, hb, slot_a(5), slot_b(5)); [[fallthrough]];
-        case 6: if constexpr (TPW >= 6) syrk_slot<D, NKS>(acc[5], slot_a(5), slot_b(5), ha, hb, slot_a(4), slot_b(4)); [[fallthrough]];
-        case 5: if constexpr (TPW >= 5) syrk_slot<D, NKS>(acc[4], slot_a(4), slot_b(4), ha, hb, slot_a(3), slot_b(3)); [[fallthrough]];
-        case 4: if constexpr (TPW >= 4) syrk_slot<D, NKS>(acc[3], slot_a(3), slot_b(3), ha, hb, slot_a(2), slot_b(2)); [[fallthrough]];
-        case 3: if constexpr (TPW >= 3) syrk_slot<D, NKS>(acc[2], slot_a(2), slot_b(2), ha, hb, slot_a(1), slot_b(1)); [[fallthrough]];
-        case 2: if constexpr (TPW >= 2) syrk_slot<D, NKS>(acc[1], slot_a(1), slot_b(1), ha, hb, slot_a(0), slot_b(0)); [[fallthrough]];
-        case 1: if constexpr (TPW >= 1) syrk_slot<D, NKS>(acc[0], slot_a(0), slot_b(0), ha, hb, slot_a(0), slot_b(0)); [[fallthrough]];
-        default: break;
+#pragma unroll
+    for (int q = TPW - 1; q >= 0; --q) {
+        if (q < nact) {
+            const int qn = q > 0 ? q - 1 : 0;
+            syrk_slot<D, NKS, (VS_SYRK_TIED && TPW <= 12)>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+        }
     }
 }
 
@@ -1405,22 +1427,8 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
         const double* ybase = sY + ylane;   // + the buffer of the pass (latency form: two Y buffers)
         auto slot_a = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1))) & 0xffu); };
         auto slot_b = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu); };
-#pragma unroll 1
-        for (int m = 0; m < NPASS; ++m) {
-            const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
-            VS_TIC();
-            // scalar table lookups of this pass's SYRK, requested before the recursion: active slots of this wavefront
-            // (a prefix) and the tile of the first slot to run
-            const int nact = kNactTab<D>.n[m][pw];
-            const int t0 = (nact > 0 ? nact - 1 : 0) * D::NWAVES + pw;
-            double* sYm = sY;
-            if constexpr (LAT) {
-                sYm = sY + (m & 1) * S::sizeY;
-                ybase = sYm + ylane;
-            }
-            const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
-            const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
-            if (rec_wave) {
+        // one pass of the recursion (nodes 2m, 2m + 1 -> the Y buffer sYm) and one pass of the SYRK (Y buffer behind ybase)
+        auto rec_pass = [&](int m, int nnodes, double* sYm) {
             load_coeffs();
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -1470,11 +1478,8 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
             }
             if (nnodes == 1)  // rows 18,19 of the last, single-node pass (k-step 4 reads rows 16..19)
                 for (int i = ptid; i < 2 * D::YS; i += D::BLOCK) sYm[18 * D::YS + i] = 0.0;
-            }
-            VS_TOC(0);
-            __syncthreads();
-            VS_TOC(1);
-            if (mm_wave) {
+        };
+        auto syrk_pass = [&](int nnodes, int nact, const double* pa0, const double* pb0) {
             // C += Y^T Y over this pass: D = A*B, A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n].
             // Columns that are not active yet are exactly zero, so skipping a tile is only an optimisation.
             if constexpr (TPW <= 12) {
@@ -1484,7 +1489,7 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
 #pragma unroll
                     for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = pa0[ks * 4 * D::YS]; hb[ks] = pb0[ks * 4 * D::YS]; }
                     if (nnodes == 2) {
-                        if (nact == TPW) syrk_all<D, 9, TPW>(acc, ha, hb, slot_a, slot_b);   // straight-line: no joins
+                        if (VS_SYRK_ALL && nact == TPW) syrk_all<D, 9, TPW>(acc, ha, hb, slot_a, slot_b);   // straight-line: no joins
                         else syrk_enter<D, 9, TPW>(nact, acc, ha, hb, slot_a, slot_b);
                     } else {
                         syrk_enter<D, 5, TPW>(nact, acc, ha, hb, slot_a, slot_b);
@@ -1514,14 +1519,107 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
                     }
                 }
             }
+        };
+        // scalar table lookups of a pass's SYRK: active slots of this wavefront (a prefix), tile of the first slot to run
+        auto first_tile = [&](int nact) { return (nact > 0 ? nact - 1 : 0) * D::NWAVES + pw; };
+        // Short horizons: the pass loop is UNROLLED and the number of slots a pass runs is a compile-time constant, the same
+        // for the four wavefronts (the maximum over them: a wavefront with fewer active tiles multiplies columns of Y
+        // that are still exactly zero).  The SYRK of a pass is then straight-line code -- a branch per slot, or any
+        // other control flow around the chains, makes the register allocator move whole accumulator tiles at the joins
+        // (measured: ~1.1k cycles per pass).  The wavefront with the most active tiles sets the pace either way.
+        auto syrk_fixed = [&](auto nks_c, auto nact_c) {
+            constexpr int NKS = decltype(nks_c)::value, NACT = decltype(nact_c)::value;
+            if constexpr (NACT > 0) {
+                double ha[SYRK_DIST], hb[SYRK_DIST];
+#pragma unroll
+                for (int ks = 0; ks < SYRK_DIST; ++ks) {
+                    ha[ks] = slot_a(NACT - 1)[ks * 4 * D::YS];
+                    hb[ks] = slot_b(NACT - 1)[ks * 4 * D::YS];
+                }
+#pragma unroll
+                for (int q = NACT - 1; q >= 0; --q) {
+                    const int qn = q > 0 ? q - 1 : 0;
+                    syrk_slot<D, NKS, VS_SYRK_TIED>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+                }
             }
-            VS_TOC(2);
-            if constexpr (!LAT) __syncthreads();  // single Y buffer: the next pass overwrites it
+        };
+        constexpr bool UNROLLED = VS_SYRK_UNROLL && TPW <= 12;
+        if constexpr (LAT) {
+            // two loops that meet at one barrier per pass: pass m + 1 of the recursion runs beside pass m of the SYRK
+            if (rec_wave) {
+#pragma unroll 1
+                for (int m = 0; m < NPASS; ++m) {
+                    rec_pass(m, (2 * m + 1 < D::N) ? 2 : 1, sY + (m & 1) * S::sizeY);
+                    __syncthreads();
+                }
+                return;   // later barriers count the live wavefronts only
+            }
+            if constexpr (UNROLLED) {
+                static_for<0, NPASS>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    VS_TIC();
+                    ybase = sY + (m & 1) * S::sizeY + ylane;
+                    VS_TOC(0);
+                    __syncthreads();
+                    VS_TOC(1);
+                    syrk_fixed(std::integral_constant<int, (2 * m + 1 < D::N) ? 9 : 5>{},
+                               std::integral_constant<int, nact_max<D>(m)>{});
+#ifdef VS_DIAG_PASS   // measurement builds: the matrix-core time of ONE pass (tools/exp_build.sh)
+                    if (m != VS_DIAG_PASS) { VS_TIC(); } else
+#endif
+                    VS_TOC(2);
+                });
+            } else {
+#pragma unroll 1
+                for (int m = 0; m < NPASS; ++m) {
+                    VS_TIC();
+                    const int nact = kNactTab<D>.n[m][pw];
+                    const int t0 = first_tile(nact);
+                    ybase = sY + (m & 1) * S::sizeY + ylane;
+                    const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
+                    const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
+                    VS_TOC(0);
+                    __syncthreads();
+                    VS_TOC(1);
+                    syrk_pass((2 * m + 1 < D::N) ? 2 : 1, nact, pa0, pb0);
+                    VS_TOC(2);
+                }
+            }
+        } else if constexpr (UNROLLED) {
+            static_for<0, NPASS>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
+                VS_TIC();
+                rec_pass(m, nnodes, sY);
+                VS_TOC(0);
+                __syncthreads();
+                VS_TOC(1);
+                syrk_fixed(std::integral_constant<int, nnodes == 2 ? 9 : 5>{}, std::integral_constant<int, nact_max<D>(m)>{});
+#ifdef VS_DIAG_PASS
+                if (m != VS_DIAG_PASS) { VS_TIC(); } else
+#endif
+                VS_TOC(2);
+                __syncthreads();  // single Y buffer: the next pass overwrites it
+            });
+        } else {
+#pragma unroll 1
+            for (int m = 0; m < NPASS; ++m) {
+                const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
+                VS_TIC();
+                const int nact = kNactTab<D>.n[m][pw];   // requested before the recursion
+                const int t0 = first_tile(nact);
+                const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
+                const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
+                rec_pass(m, nnodes, sY);
+                VS_TOC(0);
+                __syncthreads();
+                VS_TOC(1);
+                syrk_pass(nnodes, nact, pa0, pb0);
+                VS_TOC(2);
+                __syncthreads();  // single Y buffer: the next pass overwrites it
+            }
         }
         VS_TIC();
-    }
-    if constexpr (LAT) {
-        if (wave >= D::NWAVES) return;   // the recursion wavefronts are done; later barriers count the live wavefronts only
     }
     VS_STAMP(2);
     VS_REFRESH_IDS();
