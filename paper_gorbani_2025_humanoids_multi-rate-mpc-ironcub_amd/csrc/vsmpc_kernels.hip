@@ -68,6 +68,21 @@ constexpr int nact_max(int m) {
     return n;
 }
 
+// runs of consecutive SYRK passes with the same slot count and the same number of k-steps
+template <class D>
+struct PassGroups {
+    static constexpr int NPASS = (D::N + 1) / 2;
+    int start[NPASS], end[NPASS], nact[NPASS], nks[NPASS], n;
+    constexpr PassGroups() : start{}, end{}, nact{}, nks{}, n(0) {
+        for (int m = 0; m < NPASS; ++m) {
+            const int a = nact_max<D>(m), k = (2 * m + 1 < D::N) ? 9 : 5;
+            if (n > 0 && nact[n - 1] == a && nks[n - 1] == k) { end[n - 1] = m + 1; continue; }
+            start[n] = m; end[n] = m + 1; nact[n] = a; nks[n] = k; ++n;
+        }
+    }
+    static constexpr int count() { return PassGroups().n; }
+};
+
 VS_DEV double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
@@ -317,11 +332,14 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 #ifndef VS_SYRK_TIED
 #define VS_SYRK_TIED 0
 #endif
+#ifndef VS_LAT_FORM
+#define VS_LAT_FORM 1
+#endif
+#ifndef VS_UNROLL_TPW
+#define VS_UNROLL_TPW 12
+#endif
 #ifndef VS_SYRK_UNROLL
 #define VS_SYRK_UNROLL 1
-#endif
-#ifndef VS_SYRK_ALL
-#define VS_SYRK_ALL 0
 #endif
 constexpr int SYRK_DIST = VS_SYRK_DIST;
 
@@ -333,7 +351,7 @@ constexpr int SYRK_DIST = VS_SYRK_DIST;
 // tile are placed by hand: 18 behind the last instruction of a chain (CDNA3 ISA 4.5: DGEMM 16x16x4 result -> VALU
 // read/write), which cost nothing -- the matrix pipe is busy for 64 cycles with that instruction anyway -- and 2 in
 // front of the first one (vector write -> matrix read).  Within a chain the accumulator forwards back to back.
-template <class D, int NKS, bool TIED = false>
+template <class D, int NKS, bool TIED = false, bool PIN = true>
 VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __restrict__ pb, double (&ha)[SYRK_DIST],
                       double (&hb)[SYRK_DIST], const double* __restrict__ pan, const double* __restrict__ pbn) {
     static_assert(NKS >= 2 * SYRK_DIST - 1, "pipeline depth");
@@ -353,7 +371,7 @@ VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __re
         } else {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         const int n = ks + SYRK_DIST;
         if (n < NKS) {
             av[n] = pa[n * 4 * D::YS];
@@ -366,34 +384,10 @@ VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __re
             na[ks] = pan[ks * 4 * D::YS];
             nb[ks] = pbn[ks * 4 * D::YS];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = na[ks]; hb[ks] = nb[ks]; }
-}
-
-// all TPW slots of a wavefront in a row, no branch in between (passes in which every tile is active)
-template <class D, int NKS, int TPW, class SA, class SB>
-VS_DEV void syrk_all(d4 (&acc)[TPW], double (&ha)[SYRK_DIST], double (&hb)[SYRK_DIST], const SA& slot_a, const SB& slot_b) {
-#pragma unroll
-    for (int q = TPW - 1; q >= 0; --q) {
-        const int qn = q > 0 ? q - 1 : 0;
-        syrk_slot<D, NKS, VS_SYRK_TIED>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
-    }
-}
-
-// the active slots nact - 1, ..., 0 of a wavefront, one scalar branch per slot.  Every chain updates its tile in place
-// (TIED), so the joins behind the branches carry no copies.
-template <class D, int NKS, int TPW, class SA, class SB>
-VS_DEV void syrk_enter(int nact, d4 (&acc)[TPW], double (&ha)[SYRK_DIST], double (&hb)[SYRK_DIST], const SA& slot_a,
-                       const SB& slot_b) {
-#pragma unroll
-    for (int q = TPW - 1; q >= 0; --q) {
-        if (q < nact) {
-            const int qn = q > 0 ? q - 1 : 0;
-            syrk_slot<D, NKS, (VS_SYRK_TIED && TPW <= 12)>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1195,8 +1189,8 @@ VS_DEV const SolveArgs* late_args() {
 // per pass), and end after the last pass; a barrier only counts the wavefronts that are still alive, so P2..P6 are the
 // four-wavefront code unchanged.  The throughput form (two workgroups per CU) hides the recursion behind the
 // co-resident workgroup instead and needs the LDS for it.
-template <class D, bool STAMPS, bool LAT = false>
-__global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
+template <class D, bool STAMPS, int LAT = 0>
+__global__ __launch_bounds__(LAT == 1 ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* xout_, double* fmout_, int* status_out_,
                                                          int* iters_out_, double* dbgM_, double* dbgL_,
                                                          unsigned long long* stamps_) {
@@ -1353,9 +1347,9 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
         constexpr int CPT = D::CPT;
         // latency form: wavefronts NWAVES.. run the recursion (rec_wave), wavefronts 0..NWAVES-1 the SYRK (mm_wave);
         // throughput form: every wavefront does both, one after the other
-        const int pw = LAT ? (wave & (D::NWAVES - 1)) : wave;
-        const int ptid = LAT ? (tid & (D::BLOCK - 1)) : tid;
-        const bool rec_wave = !LAT || wave >= D::NWAVES, mm_wave = !LAT || wave < D::NWAVES;
+        const int pw = LAT == 1 ? (wave & (D::NWAVES - 1)) : wave;
+        const int ptid = LAT == 1 ? (tid & (D::BLOCK - 1)) : tid;
+        const bool rec_wave = LAT != 1 || wave >= D::NWAVES, mm_wave = LAT != 1 || wave < D::NWAVES;
         const int half = pw / (D::NWAVES / 2);  // scalar
         const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
         const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
@@ -1363,7 +1357,7 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
         // coefficient rows of this half: wave-uniform LDS broadcasts, re-read at the top of every pass so that they are
         // dead during the matrix-core section (the accumulator tiles stay in registers for the whole of P1..P5)
         double M1[9], Sk[9], Ce[3], sqx[3], sqh[3], sqe[3];
-        auto load_coeffs = [&]() {
+        auto load_coeffs = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -1425,10 +1419,19 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
 #pragma unroll
         for (int k = 0; k < TilePack<D>::NWORDS; ++k) tpk[k] = kTilePack<D>.w[pw][k];
         const double* ybase = sY + ylane;   // + the buffer of the pass (latency form: two Y buffers)
-        auto slot_a = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1))) & 0xffu); };
-        auto slot_b = [&](int q) { return ybase + 16 * int((tpk[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu); };
+        constexpr bool UNROLLED = VS_SYRK_UNROLL && TPW <= VS_UNROLL_TPW;
+        // In a rolled pass loop the operand addresses are loop invariants: the compiler hoists all 2 TPW of them out of the
+        // loop and, at 30 slots, spills them -- ~4k cycles of scratch reloads per pass (measured).  The packed word is
+        // therefore made opaque where it is used: one shift-and-add per operand address, in place.
+        auto slot_word = [&](int q) __attribute__((always_inline)) {
+            unsigned w = tpk[q >> 1];
+            if constexpr (!UNROLLED) asm volatile("" : "+s"(w));
+            return w;
+        };
+        auto slot_a = [&](int q) __attribute__((always_inline)) { return ybase + 16 * int((slot_word(q) >> (16 * (q & 1))) & 0xffu); };
+        auto slot_b = [&](int q) __attribute__((always_inline)) { return ybase + 16 * int((slot_word(q) >> (16 * (q & 1) + 8)) & 0xffu); };
         // one pass of the recursion (nodes 2m, 2m + 1 -> the Y buffer sYm) and one pass of the SYRK (Y buffer behind ybase)
-        auto rec_pass = [&](int m, int nnodes, double* sYm) {
+        auto rec_pass = [&](int m, int nnodes, double* sYm) __attribute__((always_inline)) {
             load_coeffs();
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -1479,55 +1482,12 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
             if (nnodes == 1)  // rows 18,19 of the last, single-node pass (k-step 4 reads rows 16..19)
                 for (int i = ptid; i < 2 * D::YS; i += D::BLOCK) sYm[18 * D::YS + i] = 0.0;
         };
-        auto syrk_pass = [&](int nnodes, int nact, const double* pa0, const double* pb0) {
-            // C += Y^T Y over this pass: D = A*B, A[m][kk] = Y[kk][16 i + m], B[kk][n] = Y[kk][16 j + n].
-            // Columns that are not active yet are exactly zero, so skipping a tile is only an optimisation.
-            if constexpr (TPW <= 12) {
-                if (nact > 0) {
-                    // fall-through switch over the slots (see syrk_slot); head operands of the first slot to run
-                    double ha[SYRK_DIST], hb[SYRK_DIST];
-#pragma unroll
-                    for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = pa0[ks * 4 * D::YS]; hb[ks] = pb0[ks * 4 * D::YS]; }
-                    if (nnodes == 2) {
-                        if (VS_SYRK_ALL && nact == TPW) syrk_all<D, 9, TPW>(acc, ha, hb, slot_a, slot_b);   // straight-line: no joins
-                        else syrk_enter<D, 9, TPW>(nact, acc, ha, hb, slot_a, slot_b);
-                    } else {
-                        syrk_enter<D, 5, TPW>(nact, acc, ha, hb, slot_a, slot_b);
-                    }
-                }
-            } else {
-                // long horizons (30 slots, one workgroup per CU, 512 registers): one scalar branch per slot in ascending
-                // order; the joins cost accumulator copies, which this register budget affords
-                double ha[SYRK_DIST], hb[SYRK_DIST];
-#pragma unroll
-                for (int ks = 0; ks < SYRK_DIST; ++ks) { ha[ks] = slot_a(0)[ks * 4 * D::YS]; hb[ks] = slot_b(0)[ks * 4 * D::YS]; }
-                if (nnodes == 2) {
-#pragma unroll
-                    for (int q = 0; q < TPW; ++q) {
-                        if (q < nact) {
-                            const int qn = q + 1 < TPW ? q + 1 : q;
-                            syrk_slot<D, 9>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < TPW; ++q) {
-                        if (q < nact) {
-                            const int qn = q + 1 < TPW ? q + 1 : q;
-                            syrk_slot<D, 5>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
-                        }
-                    }
-                }
-            }
-        };
-        // scalar table lookups of a pass's SYRK: active slots of this wavefront (a prefix), tile of the first slot to run
-        auto first_tile = [&](int nact) { return (nact > 0 ? nact - 1 : 0) * D::NWAVES + pw; };
         // Short horizons: the pass loop is UNROLLED and the number of slots a pass runs is a compile-time constant, the same
         // for the four wavefronts (the maximum over them: a wavefront with fewer active tiles multiplies columns of Y
         // that are still exactly zero).  The SYRK of a pass is then straight-line code -- a branch per slot, or any
         // other control flow around the chains, makes the register allocator move whole accumulator tiles at the joins
         // (measured: ~1.1k cycles per pass).  The wavefront with the most active tiles sets the pace either way.
-        auto syrk_fixed = [&](auto nks_c, auto nact_c) {
+        auto syrk_fixed = [&](auto nks_c, auto nact_c) __attribute__((always_inline)) {
             constexpr int NKS = decltype(nks_c)::value, NACT = decltype(nact_c)::value;
             if constexpr (NACT > 0) {
                 double ha[SYRK_DIST], hb[SYRK_DIST];
@@ -1539,14 +1499,37 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
 #pragma unroll
                 for (int q = NACT - 1; q >= 0; --q) {
                     const int qn = q > 0 ? q - 1 : 0;
-                    syrk_slot<D, NKS, VS_SYRK_TIED>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+                    syrk_slot<D, NKS, VS_SYRK_TIED, LAT != 2>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+#ifdef VS_DIAG_SPLIT   // measurement builds: time of the first chain of every pass -> sub-phase 3
+                    if (q == NACT - 1) VS_TOC(3);
+#endif
                 }
             }
         };
-        constexpr bool UNROLLED = VS_SYRK_UNROLL && TPW <= 12;
-        if constexpr (LAT) {
+        if constexpr (LAT == 2) {
+            // four wavefronts, two Y buffers: the recursion of pass m + 1 and the SYRK of pass m in ONE instruction stream
+            // (no scheduling pins: the compiler fills the 64-cycle shadow of every matrix instruction with the
+            // recursion's loads, address arithmetic and stores; FP64 vector instructions share the unit with the matrix
+            // instructions and add their own issue time)
+            rec_pass(0, (1 < D::N) ? 2 : 1, sY);
+            __syncthreads();
+            static_for<0, NPASS>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                VS_TIC();
+                ybase = sY + (m & 1) * S::sizeY + ylane;
+                if constexpr (m + 1 < NPASS) rec_pass(m + 1, (2 * m + 3 < D::N) ? 2 : 1, sY + ((m + 1) & 1) * S::sizeY);
+                syrk_fixed(std::integral_constant<int, (2 * m + 1 < D::N) ? 9 : 5>{},
+                           std::integral_constant<int, nact_max<D>(m)>{});
+                VS_TOC(2);
+                __syncthreads();
+            });
+        } else if constexpr (LAT == 1) {
+            static_assert(UNROLLED, "the latency forms exist for the short horizons");
             // two loops that meet at one barrier per pass: pass m + 1 of the recursion runs beside pass m of the SYRK
             if (rec_wave) {
+#ifdef VS_PRODUCER_PRIO
+                __builtin_amdgcn_s_setprio(VS_PRODUCER_PRIO);
+#endif
 #pragma unroll 1
                 for (int m = 0; m < NPASS; ++m) {
                     rec_pass(m, (2 * m + 1 < D::N) ? 2 : 1, sY + (m & 1) * S::sizeY);
@@ -1555,7 +1538,7 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
                 return;   // later barriers count the live wavefronts only
             }
             if constexpr (UNROLLED) {
-                static_for<0, NPASS>([&](auto mc) {
+                static_for<0, NPASS>([&](auto mc) __attribute__((always_inline)) {
                     constexpr int m = decltype(mc)::value;
                     VS_TIC();
                     ybase = sY + (m & 1) * S::sizeY + ylane;
@@ -1569,24 +1552,9 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
 #endif
                     VS_TOC(2);
                 });
-            } else {
-#pragma unroll 1
-                for (int m = 0; m < NPASS; ++m) {
-                    VS_TIC();
-                    const int nact = kNactTab<D>.n[m][pw];
-                    const int t0 = first_tile(nact);
-                    ybase = sY + (m & 1) * S::sizeY + ylane;
-                    const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
-                    const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
-                    VS_TOC(0);
-                    __syncthreads();
-                    VS_TOC(1);
-                    syrk_pass((2 * m + 1 < D::N) ? 2 : 1, nact, pa0, pb0);
-                    VS_TOC(2);
-                }
             }
         } else if constexpr (UNROLLED) {
-            static_for<0, NPASS>([&](auto mc) {
+            static_for<0, NPASS>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value;
                 constexpr int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
                 VS_TIC();
@@ -1602,22 +1570,26 @@ __global__ __launch_bounds__(LAT ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_
                 __syncthreads();  // single Y buffer: the next pass overwrites it
             });
         } else {
+            // long horizons: consecutive passes with the same slot count share one rolled loop whose body is straight-line
+            // (see PassGroups): the code stays small (one set of chains per DISTINCT slot count, not per pass)
+            static_for<0, PassGroups<D>::count()>([&](auto gc) __attribute__((always_inline)) {
+                constexpr PassGroups<D> pg{};
+                constexpr int g = decltype(gc)::value;
 #pragma unroll 1
-            for (int m = 0; m < NPASS; ++m) {
-                const int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
-                VS_TIC();
-                const int nact = kNactTab<D>.n[m][pw];   // requested before the recursion
-                const int t0 = first_tile(nact);
-                const double* pa0 = ybase + 16 * kTileTab<D>.ti[t0];
-                const double* pb0 = ybase + 16 * kTileTab<D>.tj[t0];
-                rec_pass(m, nnodes, sY);
-                VS_TOC(0);
-                __syncthreads();
-                VS_TOC(1);
-                syrk_pass(nnodes, nact, pa0, pb0);
-                VS_TOC(2);
-                __syncthreads();  // single Y buffer: the next pass overwrites it
-            }
+                for (int m = pg.start[g]; m < pg.end[g]; ++m) {
+                    VS_TIC();
+                    rec_pass(m, pg.nks[g] == 9 ? 2 : 1, sY);
+                    VS_TOC(0);
+                    __syncthreads();
+                    VS_TOC(1);
+                    syrk_fixed(std::integral_constant<int, pg.nks[g]>{}, std::integral_constant<int, pg.nact[g]>{});
+#ifdef VS_DIAG_PASS
+                    if (m != VS_DIAG_PASS) { VS_TIC(); } else
+#endif
+                    VS_TOC(2);
+                    __syncthreads();  // single Y buffer: the next pass overwrites it
+                }
+            });
         }
         VS_TIC();
     }
@@ -2125,7 +2097,7 @@ int set_kernel_form(int form) {
     return prev;
 }
 
-template <class D, bool STAMPS, bool LAT>
+template <class D, bool STAMPS, int LAT>
 static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
                                  unsigned long long* stamps, hipStream_t stream) {
@@ -2138,7 +2110,7 @@ static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in,
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((solve_kernel<D, STAMPS, LAT>), dim3(batch), dim3(LAT ? 2 * D::BLOCK : D::BLOCK), lds, stream,
+    hipLaunchKernelGGL((solve_kernel<D, STAMPS, LAT>), dim3(batch), dim3(LAT == 1 ? 2 * D::BLOCK : D::BLOCK), lds, stream,
                        cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
     return hipGetLastError();
 }
@@ -2156,10 +2128,10 @@ static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batc
         if ((e = device_cus(dev, &cus)) != hipSuccess) return e;
         const int form = forced_form();
         if (form == 2 || (form == 0 && batch <= cus))
-            return launch_solve_f<D, STAMPS, true>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
+            return launch_solve_f<D, STAMPS, VS_LAT_FORM>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
                                                    stamps, stream);
     }
-    return launch_solve_f<D, STAMPS, false>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
+    return launch_solve_f<D, STAMPS, 0>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
                                             stream);
 }
 
