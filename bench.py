@@ -53,6 +53,17 @@ def cpu_baseline(cfg_name: str, inputs: np.ndarray, budget_s: float = 15.0):
                       f"active set), {dt:.1f} s; {note}"}
 
 
+def kernel_form(mpc, batch, dev):
+    """Which form of the solve kernel a launch of `batch` instances takes (include/vsmpc.h, vsmpc_set_kernel_form)."""
+    import torch
+    forced = os.environ.get("VSMPC_FORM", "")[:1]
+    two_forms = mpc.n_p <= 128          # horizons whose wavefronts fit 256 registers
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    latency = two_forms and (forced == "l" or (forced != "t" and batch <= cus))
+    return ("latency: 8 wavefronts, one workgroup per CU" if latency
+            else ("throughput: 4 wavefronts, two workgroups per CU" if two_forms else "4 wavefronts, one workgroup per CU"))
+
+
 def parity_sample(cfg_name: str, inputs: np.ndarray, x: np.ndarray, k: int = 8) -> float:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vsmpc_ref as ref
@@ -123,6 +134,7 @@ def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, wor
         rec = {"name": spec["name"], "config": spec["config"], "workload": spec["workload"], "batch_per_gpu": B,
                "n_gpus": world, "steps": spec["steps"], "value": B * world * spec["steps"] / elapsed, "unit": "solves/s",
                "ms_per_step": 1e3 * elapsed / spec["steps"], "kernel": mpc.kernel_name,
+               "kernel_form": kernel_form(mpc, B, dev),
                "kernel_us_per_launch": kernel_ms * 1e3, "kernel_us_per_256": kernel_ms * 1e3 * 256 / B,
                "roofline_frac": tf / FP64_PEAK_TFLOPS, "achieved_tflops": tf,
                "solved": int(cnt[0].item()), "instances_per_step": B * world,
@@ -247,7 +259,8 @@ def main():
                        "parallelism": f"batch split over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,
-                         "kernel": mpc.kernel_name, "kernel_us_per_launch": kernel_ms * 1e3,
+                         "kernel": mpc.kernel_name, "kernel_form": kernel_form(mpc, B, dev),
+                         "kernel_us_per_launch": kernel_ms * 1e3,
                          "alg_flops_per_solve": F_ALG[args.config], "alg_bytes_per_solve": BYTES_ALG[args.config],
                          "hbm_frac_informational": BYTES_ALG[args.config] * count / (kernel_ms * 1e-3) / 8.0e12},
             "solved": total_solved, "instances_per_step": total,

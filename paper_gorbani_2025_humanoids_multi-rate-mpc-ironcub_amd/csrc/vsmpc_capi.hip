@@ -42,9 +42,19 @@ struct vsmpc_handle {
     double* d_stage;      // device view of the same allocation (its own base pointer: the two views are unrelated addresses)
 };
 
+#ifndef VS_HOST_FLAGS
+#define VS_HOST_FLAGS hipHostMallocDefault
+#endif
 constexpr int ZC_MAX = 8;  // largest batch served through the mapped staging buffer
-constexpr int PIPE_CHUNK = 512;   // instances per chunk of the pipelined host-pointer entry (one round of two workgroups per CU)
-constexpr int PIPE_STREAMS = 4;
+#ifndef VS_PIPE_CHUNK
+#define VS_PIPE_CHUNK 1024
+#endif
+#ifndef VS_PIPE_STREAMS
+#define VS_PIPE_STREAMS 2
+#endif
+constexpr int PIPE_CHUNK = VS_PIPE_CHUNK;   // instances per chunk of the pipelined host-pointer entry
+constexpr int PIPE_STREAMS = VS_PIPE_STREAMS;
+static_assert(PIPE_STREAMS >= 1 && PIPE_STREAMS <= 4, "vsmpc_handle::pipe holds four streams");
 
 // resident closed-loop state of a batch (uses the handle's record / first-move / status buffers as its per-tick scratch)
 struct vsmpc_rollout {
@@ -656,7 +666,7 @@ int vsmpc_set_kernel_form(int form) {
 
 void* vsmpc_alloc_host(size_t bytes) {
     void* p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (bytes == 0 || hipHostMalloc(&p, bytes, VS_HOST_FLAGS) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 
