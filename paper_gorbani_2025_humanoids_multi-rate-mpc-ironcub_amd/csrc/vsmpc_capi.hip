@@ -42,9 +42,6 @@ struct vsmpc_handle {
     double* d_stage;      // device view of the same allocation (its own base pointer: the two views are unrelated addresses)
 };
 
-#ifndef VS_HOST_FLAGS
-#define VS_HOST_FLAGS hipHostMallocDefault
-#endif
 constexpr int ZC_MAX = 8;  // largest batch served through the mapped staging buffer
 #ifndef VS_PIPE_CHUNK
 #define VS_PIPE_CHUNK 1024
@@ -275,6 +272,20 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         if (iters) memcpy(iters, hit, B * sizeof(int));
         return VSMPC_OK;
     }
+    // Pinned output buffers (hipHostMalloc / vsmpc_alloc_host) are written by the kernel itself over PCIe (16 B per lane
+    // posted writes): no device-to-host copies, no copy launches (batch 4096, all outputs: 1.01 ms against 1.11 ms with
+    // one copy of the trajectories behind the last chunk; profiles/r02_v11_hostpath.json).
+    auto device_view = [](const void* host) -> void* {
+        if (host == nullptr) return nullptr;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    };
+    double* zx = static_cast<double*>(device_view(x));
+    double* zfm = static_cast<double*>(device_view(first_move));
+    int* zst = static_cast<int*>(device_view(status));
+    int* zit = static_cast<int*>(device_view(iters));
+    const bool direct = (x == nullptr || zx) && (first_move == nullptr || zfm) && zst && (iters == nullptr || zit);
     // chunks of PIPE_CHUNK instances rotate over the handle's streams: upload(k+1) | solve(k) | download(k-1)
     // overlap when the caller's buffers are pinned (hipHostMalloc / vsmpc_alloc_host); with pageable buffers the
     // runtime stages the copies itself and the chunks still overlap with the kernels
@@ -287,6 +298,12 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         const size_t o = size_t(first), N = size_t(n);
         hipStream_t ps = h->pipe[k % nstreams];
         HIP_TRY(hipMemcpyAsync(h->d_in + o * h->n_in, in + o * h->n_in, N * h->n_in * sizeof(double), hipMemcpyHostToDevice, ps));
+        if (direct) {
+            HIP_TRY(launch_solve(h->variant, h->dev, h->d_in + o * h->n_in, n, x ? zx + o * h->n_var : nullptr,
+                                 first_move ? zfm + o * VSMPC_FM_SIZE : nullptr, zst + o, iters ? zit + o : nullptr,
+                                 nullptr, nullptr, nullptr, ps));
+            continue;
+        }
         HIP_TRY(launch_solve(h->variant, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
                              h->d_fm + o * VSMPC_FM_SIZE, h->d_status + o, h->d_iters + o, nullptr, nullptr, nullptr, ps));
         if (x) HIP_TRY(hipMemcpyAsync(x + o * h->n_var, h->d_x + o * h->n_var, N * h->n_var * sizeof(double), hipMemcpyDeviceToHost, ps));
@@ -666,7 +683,7 @@ int vsmpc_set_kernel_form(int form) {
 
 void* vsmpc_alloc_host(size_t bytes) {
     void* p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, VS_HOST_FLAGS) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 

@@ -223,6 +223,46 @@ def test_device_entry_matches_host_entry(mpc, synth, layout):
     assert (d_st.cpu().numpy() == layout.STATUS_SOLVED).all()
 
 
+def test_pinned_buffers_take_the_direct_store_path(mpc, solver_mod, synth, layout):
+    """Callers that hand pinned buffers (vsmpc_alloc_host) get the results written by the kernel straight into them
+    (no device-to-host copies); same bits as through pageable buffers, also with optional outputs left out."""
+    import importlib
+    _lib = importlib.import_module(solver_mod.__name__.rsplit(".", 1)[0] + "._lib")
+    lib = _lib.load()
+    cfg = layout.paper_config()
+    B = 200                                     # > 8 (mapped staging), not a multiple of anything
+    big = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=B)
+    recs = synth.make_batch(cfg, B, workload="takeoff")
+    ref_x, ref_fm, ref_st, ref_it = big.solve(recs)
+
+    def pinned(shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = lib.vsmpc_alloc_host(n)
+        assert ptr
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), (n,)).view(dtype).reshape(shape), ptr
+
+    bufs = [pinned((B, cfg.n_in), np.float64), pinned((B, cfg.n_var), np.float64), pinned((B, 24), np.float64),
+            pinned((B,), np.int32), pinned((B,), np.int32)]
+    try:
+        (inp, _), (x, _), (fm, _), (st, _), (it, _) = bufs
+        inp[:] = recs
+        x[:] = np.nan; fm[:] = np.nan; st[:] = -7; it[:] = -7
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(lib.vsmpc_solve_batch(big._h, vp(inp), B, vp(x), vp(fm), vp(st), vp(it), None), "vsmpc_solve_batch")
+        np.testing.assert_array_equal(x, ref_x)
+        np.testing.assert_array_equal(fm, ref_fm)
+        np.testing.assert_array_equal(st, ref_st)
+        np.testing.assert_array_equal(it, ref_it)
+        st[:] = -7; fm[:] = np.nan
+        _lib.check(lib.vsmpc_solve_batch(big._h, vp(inp), B, None, vp(fm), vp(st), None, None), "vsmpc_solve_batch")
+        np.testing.assert_array_equal(fm, ref_fm)
+        np.testing.assert_array_equal(st, ref_st)
+    finally:
+        for _, ptr in bufs:
+            lib.vsmpc_free_host(ptr)
+        big.close()
+
+
 def test_latency_and_throughput_forms_are_bit_identical(mpc, solver_mod, synth, layout):
     """The two forms of the solve kernel (include/vsmpc.h, vsmpc_set_kernel_form) run the same arithmetic in the same
     order: outputs, statuses, iteration counts, condensed Hessian and factor must be equal bit for bit."""

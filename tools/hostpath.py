@@ -25,8 +25,9 @@ for B in (256, 4096):
             st, p3 = pinned((B,), np.int32); it, p4 = pinned((B,), np.int32)
         else:
             inp = recs.copy(); x = np.empty((B, cfg.n_var)); fm = np.empty((B, 24)); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
-        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        call = lambda: _lib.check(lib.vsmpc_solve_batch(m._h, ptr(inp), B, ptr(x), ptr(fm), ptr(st), ptr(it), None))
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)    # taken once: building the ctypes view of a large array per call costs ms
+        p_in, p_x, p_fm, p_st, p_it = ptr(inp), ptr(x), ptr(fm), ptr(st), ptr(it)
+        call = lambda: _lib.check(lib.vsmpc_solve_batch(m._h, p_in, B, p_x, p_fm, p_st, p_it, None))
         for _ in range(5): call()
         t = time.perf_counter(); n = 30
         for _ in range(n): call()
@@ -34,7 +35,7 @@ for B in (256, 4096):
         assert (st == 1).all()
         out[f"{kind}:{B}"] = {"us_per_call": dt * 1e6, "solves_per_s": B / dt}
         # first-move-only output (x = NULL): the harness' own use
-        call2 = lambda: _lib.check(lib.vsmpc_solve_batch(m._h, ptr(inp), B, None, ptr(fm), ptr(st), ptr(it), None))
+        call2 = lambda: _lib.check(lib.vsmpc_solve_batch(m._h, p_in, B, None, p_fm, p_st, p_it, None))
         for _ in range(3): call2()
         t = time.perf_counter()
         for _ in range(n): call2()
