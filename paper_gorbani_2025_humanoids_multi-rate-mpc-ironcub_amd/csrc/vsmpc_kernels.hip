@@ -8,7 +8,10 @@
 //                  column), then the sensitivity recursion in registers: thread (half, col) carries the
 //                  linear-momentum half (p, h_lin, e_pos) or the angular half (rpy, h_ang, e_rpy) of
 //                  one condensed column; two nodes (36 weighted rows = 9 exact MFMA k-steps) per pass;
-//                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers
+//                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers, every pass a
+//                  straight-line sequence of per-tile chains (compile-time slot count).  Two forms: throughput (four
+//                  wavefronts, two workgroups per CU) and latency (eight wavefronts, the recursion of the next pass
+//                  beside the SYRK of this one; batches of at most one instance per CU)
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
 //   P3 cholesky    right-looking LL^T on 16x16 tiles; the trailing matrix AND the finished factor stay in registers,
@@ -315,16 +318,20 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 // ------------------------------------------------------------------------------------------------
 // SYRK of P1, one accumulator tile (slot) at a time: NKS k-steps of 4 rows as ONE dependent chain on the tile's
 // accumulator (a dependent v_mfma_f64_16x16x4_f64 issues every 64 cycles, like independent ones).
-//   * The active slots of a wavefront are a prefix 0..nact-1; the caller enters a straight-line sequence
-//     slot nact-1, ..., slot 0 through a switch with fall-through.  Every accumulator reaches its own chain unmodified
-//     on every path, so no control-flow join carries a modified accumulator: no copies of the eight accumulator
-//     registers, no second register set, no hazard stalls at joins (through v9 a pass was one stream over all active
-//     slots instantiated per slot count, whose joins cost a second set of accumulator registers -- unaffordable at two
-//     workgroups per CU).
+//   * The slots a pass runs are a prefix NACT-1, ..., 0 of the stage-sorted tile table, and NACT is a COMPILE-TIME
+//     constant of the pass, the same for the four wavefronts (the maximum over them; a wavefront with fewer active
+//     tiles multiplies columns of Y that are still exactly zero).  The chains of a pass are therefore straight-line
+//     code.  Every earlier form with control flow around the chains (an instantiation per slot count through v9, a
+//     fall-through switch, a branch per slot) made the register allocator move whole accumulator tiles at the joins
+//     and the loop back-edge: ~1.1k cycles per pass whatever the number of chains (38.8k cycles of matrix-core
+//     section against a floor of 29.4k; now 31.6k).  Short horizons unroll the pass loop, long ones run one rolled
+//     loop per distinct slot count (PassGroups).
 //   * Operand loads are software-pipelined SYRK_DIST instructions ahead ACROSS slots and pinned with sched_barrier:
-//     the wave's stream blocks at every MFMA issue until the pipe is free (64 cycles), an LDS read returns in ~130, so
-//     a load issued behind instruction e is there for instruction e + 3.  `ha`/`hb` carry the first SYRK_DIST operand
-//     pairs of the slot in and those of the NEXT slot (slot q - 1) out.
+//     the wave's stream blocks at every MFMA issue until the pipe is free (64 cycles), an LDS read returns in ~130.
+//     `ha`/`hb` carry the first SYRK_DIST operand pairs of the slot in and those of the NEXT slot (slot q - 1) out.
+// Build-time switches (measurement variants, tools/exp_build.sh): VS_SYRK_DIST prefetch distance, VS_SYRK_TIED inline
+// assembly with a tied accumulator, VS_LAT_FORM 1 | 2 the latency form (2 = four wavefronts, recursion and SYRK in one
+// stream), VS_SYRK_UNROLL / VS_UNROLL_TPW unrolled passes up to that many slots per wavefront.
 // ------------------------------------------------------------------------------------------------
 #ifndef VS_SYRK_DIST
 #define VS_SYRK_DIST 2
