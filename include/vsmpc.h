@@ -211,7 +211,12 @@ int vsmpc_timing_end(vsmpc_handle* h, void* stream, int launches, float* ms_per_
 #define VSMPC_PS_U 28       /* 4 throttle command in percent (held between MPC moves) */
 #define VSMPC_PS_TDES 32    /* 4 last MPC thrust reference   (QPInput::getThrustDesMPC)    */
 #define VSMPC_PS_TDDES 36   /* 4 last MPC thrust-rate reference                            */
-#define VSMPC_PLANT_STATE 40
+/* jet plant option (vsmpc_rollout_set_jet_plant, include/vsmpc_jet.h): NN thrust dynamics + EKF estimates; unused and
+ * untouched with the polynomial jet plant */
+#define VSMPC_PS_TNN 40     /* 4 thrust of the LSTM jet plant (float32 values), fed back to it     */
+#define VSMPC_PS_EST 44     /* 8 EKF estimate (T, Tdot) per jet: what the MPC sees as measurement  */
+#define VSMPC_PS_EKFP 52    /* 16 EKF covariance per jet, 2x2 row-major                           */
+#define VSMPC_PLANT_STATE 68
 /* Plant parameters per instance (constant over a rollout), VSMPC_PLANT_PARAMS doubles: */
 #define VSMPC_PP_MASS 0
 #define VSMPC_PP_INERTIA_B 1   /*   9 body-frame locked inertia, row-major                                          */

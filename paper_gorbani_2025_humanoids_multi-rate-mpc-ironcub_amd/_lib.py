@@ -21,7 +21,7 @@ EXPORTS = (
     "vsmpc_set_kernel_form",
     # include/vsmpc_jet.h
     "vsmpc_jet_create", "vsmpc_jet_destroy", "vsmpc_jet_nn_step", "vsmpc_jet_nn_sequence", "vsmpc_jet_ekf_update",
-    "vsmpc_jet_plant_run", "vsmpc_jet_plant_run_device",
+    "vsmpc_jet_plant_run", "vsmpc_jet_plant_run_device", "vsmpc_rollout_set_jet_plant",
 )
 
 _lib = None
@@ -89,6 +89,8 @@ def load():
     lib.vsmpc_free_host.restype = None
     lib.vsmpc_set_kernel_form.argtypes = [c_int]
     lib.vsmpc_set_kernel_form.restype = c_int
+    lib.vsmpc_rollout_set_jet_plant.argtypes = [vp, vp, dp, dp]
+    lib.vsmpc_rollout_set_jet_plant.restype = c_int
     fp = ctypes.c_void_p
     lib.vsmpc_jet_create.argtypes = [fp, fp, fp, fp, fp, fp, dp, c_int, c_int, c_int, ctypes.POINTER(vp)]
     lib.vsmpc_jet_create.restype = c_int

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "vsmpc_launch.hpp"
+#include "../../include/vsmpc_jet.h"
 
 using namespace vsmpc;
 
@@ -588,6 +589,28 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
                           r->d_tstate, r->d_rec, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     r->valid = 1;
+    return VSMPC_OK;
+}
+
+// include/vsmpc_jet.h
+int vsmpc_rollout_set_jet_plant(vsmpc_rollout* r, vsmpc_jet* j, const double* Q, const double* R) {
+    if (r == nullptr || (j != nullptr && (Q == nullptr || R == nullptr))) return VSMPC_ERR_INVALID_ARG;
+    RolloutDev rd = r->rd;
+    rd.jet_nn = 0;
+    rd.jet_w = nullptr;
+    if (j != nullptr) {
+        int dev = -1;
+        jet_plant_view(j, &rd.jet_w, &rd.jet_hidden, rd.jet_norm, &dev);
+        if (dev != r->h->device) return VSMPC_ERR_INVALID_ARG;
+        rd.jet_nn = 1;
+        for (int k = 0; k < 4; ++k) { rd.ekf_q[k] = Q[k]; rd.ekf_r[k] = R[k]; }
+    }
+    r->rd = rd;
+    // the captured tick graph holds the old launch arguments, and the record of the next tick was built from the other
+    // set of measurements: rebuild both
+    if (r->gexec) { (void)hipGraphExecDestroy(r->gexec); r->gexec = nullptr; }
+    r->graph_state = 0;
+    r->valid = 0;                         // vsmpc_rollout_reset before the next run
     return VSMPC_OK;
 }
 

@@ -5,6 +5,8 @@
 
 #include "vsmpc_device.hpp"
 
+struct vsmpc_jet;   // include/vsmpc_jet.h
+
 namespace vsmpc {
 
 enum Variant { VARIANT_NONE = 0 };  // 1.. = position in csrc/vsmpc_horizons.def
@@ -32,7 +34,14 @@ struct RolloutDev {
     int n_ts;         // doubles of per-instance tick state (reference window, RPY unwrap: see vsmpc_rollout.hip)
     int alpha_up;     // up-sampling factor of the alpha-gravity track (TrajectoryManager.cpp:23-39)
     double period_mpc, alpha_dt;
+    // jet plant option (vsmpc_rollout_set_jet_plant): LSTM thrust dynamics + EKF estimates instead of the polynomial model
+    int jet_nn, jet_hidden;
+    const float* jet_w;          // device: wih col 0 [4H] | wih col 1 [4H] | b_ih [4H] | b_hh [4H] | fc_w [H] | fc_b
+    double jet_norm[4];          // thrust mean / std, throttle mean / std of the checkpoint
+    double ekf_q[4], ekf_r[4];
 };
+// view of a jet handle for the rollout (vsmpc_jet.hip)
+void jet_plant_view(const ::vsmpc_jet* j, const float** w, int* hidden, double norm[4], int* device);
 struct RolloutCtl {   // device-resident per-run control block of the rollout
     double* log;      // [ticks of this run][batch][VSMPC_ROLLOUT_LOG] or nullptr
     int tick_base;    // tick counter at the start of the run

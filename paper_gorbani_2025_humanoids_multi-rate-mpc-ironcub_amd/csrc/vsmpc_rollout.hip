@@ -29,6 +29,7 @@
 // (bilinear) jet map A_mom(q) T and the non-linear polynomial jet model (utils/src/JetModel.cpp:29-64), integrated
 // explicitly.
 #include "vsmpc_device.hpp"
+#include "vsmpc_jet_device.hpp"
 #include "vsmpc_launch.hpp"
 
 namespace vsmpc {
@@ -187,10 +188,14 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
         for (int j = 0; j < 8; ++j) acc += p[VSMPC_PP_DJ + 24 * j + lane] * (s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j]);
         r[VSMPC_IN_AMOM + lane] = acc;
     }
+    // thrusts and thrust rates as the controller sees them: the plant's own with the polynomial jet plant, the EKF
+    // estimates with the NN jet plant (the harness hands the estimate to Robot::setJetThrusts)
+    auto meas_T = [&](int i) { return rd.jet_nn ? s[VSMPC_PS_EST + 2 * i] : s[VSMPC_PS_T + i]; };
+    auto meas_Td = [&](int i) { return rd.jet_nn ? s[VSMPC_PS_EST + 2 * i + 1] : s[VSMPC_PS_TD + i]; };
     if (lane < 48) {
         const int row = lane >> 3, j = lane & 7;   // row 0..5 of DJ[j] T
         double acc = 0.0;
-        for (int c = 0; c < 4; ++c) acc += p[VSMPC_PP_DJ + 24 * j + 4 * row + c] * s[VSMPC_PS_T + c];
+        for (int c = 0; c < 4; ++c) acc += p[VSMPC_PP_DJ + 24 * j + 4 * row + c] * meas_T(c);
         if (row < 3) r[VSMPC_IN_LLIN + 8 * row + j] = acc;
         else r[VSMPC_IN_LANG + 8 * (row - 3) + j] = acc;
     }
@@ -202,12 +207,14 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
         r[VSMPC_IN_INERTIA + 3 * i + j] = acc;
     }
     // X0 (constraintsVSMPC.cpp:206-230): RPY enters unwrapped
-    if (lane < 20) r[VSMPC_IN_X0 + lane] = (lane >= 6 && lane < 9) ? rpy_old[lane - 6] + two_pi * n_turns[lane - 6] : s[lane];
+    if (lane < 20)
+        r[VSMPC_IN_X0 + lane] = (lane >= 6 && lane < 9) ? rpy_old[lane - 6] + two_pi * n_turns[lane - 6]
+                                : (lane >= 16 ? meas_Td(lane - 16) : (lane >= 12 ? meas_T(lane - 12) : s[lane]));
     if (lane >= 20 && lane < 29) r[VSMPC_IN_WRB + lane - 20] = R[lane - 20];
     if (lane >= 32 && lane < 36) {
         const int i = lane - 32;
-        r[VSMPC_IN_T0 + i] = s[VSMPC_PS_T + i];          // useEstimatedThrust = true (systemDynamicsVSMPC.cpp:401-404)
-        r[VSMPC_IN_TD0 + i] = s[VSMPC_PS_TD + i];
+        r[VSMPC_IN_T0 + i] = meas_T(i);                  // useEstimatedThrust = true (systemDynamicsVSMPC.cpp:401-404)
+        r[VSMPC_IN_TD0 + i] = meas_Td(i);
         r[VSMPC_IN_UPREV + i] = s[VSMPC_PS_U + i];
         r[VSMPC_IN_TDES + i] = s[VSMPC_PS_TDES + i];
         r[VSMPC_IN_TDDES + i] = s[VSMPC_PS_TDDES + i];
@@ -266,8 +273,11 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
                                                             double* __restrict__ rec_next) {
     __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9], R[9], om[3];
     __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES], ts[12 * MAX_STAGES + 8];
+    __shared__ float jw[17 * JET_HMAX + 1];   // LSTM weights of the jet plant option
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
+    if (rd.jet_nn)
+        for (int e = lane; e < 17 * rd.jet_hidden + 1; e += RO_BLOCK) jw[e] = rd.jet_w[e];
     for (int e = lane; e < rd.n_ts; e += RO_BLOCK) ts[e] = tstate[size_t(b) * rd.n_ts + e];
     stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
     stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
@@ -353,6 +363,8 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
                 d = lane == 6 ? omv[0] + sr * tp * omv[1] + cr * tp * omv[2]
                   : lane == 7 ? cr * omv[1] - sr * omv[2]
                               : (sr * omv[1] + cr * omv[2]) / cp;
+            } else if (rd.jet_nn) {                           // thrusts follow the NN below, not an ODE
+                d = 0.0;
             } else if (lane < 16) {                           // T' = Tdot
                 d = x[lane + 4];
             } else if (lane < 20) {                           // T'' = sigma_T (f + g v(u))  (JetModel.cpp:29-64)
@@ -363,6 +375,37 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
             __syncthreads();                                  // every lane has read x before anyone updates it
             if (lane < 20) x[lane] += h * d;
             __syncthreads();
+            if (rd.jet_nn) {
+                // jet plant option, one plant step (ironcub_mujoco_simulator.py:128-133,393-396): the NN advances every
+                // jet's thrust from its own previous output (hidden units over the lanes), then the jet's EKF takes the
+                // NN's (T, Tdot) as measurement.  The forces of the NEXT sub-step see the new NN thrust.
+                const JetNorm nm{rd.jet_norm[0], rd.jet_norm[1], rd.jet_norm[2], rd.jet_norm[3]};
+                float Tn_mine = 0.0f, Tdn_mine = 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    float x0, x1;
+                    jet_normalize(nm, float(s[VSMPC_PS_TNN + j]), float(s[VSMPC_PS_U + j]), x0, x1);
+                    const float out = lstm_step_from_zero_wave(jw, rd.jet_hidden, x0, x1, lane);
+                    const float Tn = (x0 + out * float(h)) * float(nm.thrust_std) + float(nm.thrust_mean);
+                    const float Tdn = out * float(nm.thrust_std);
+                    if (lane == j) { Tn_mine = Tn; Tdn_mine = Tdn; }
+                }
+                __syncthreads();                              // every lane has read s[TNN] before lanes 0..3 update it
+                if (lane < 4) {
+                    Ekf2 cv;
+                    for (int k = 0; k < 4; ++k) { cv.q[k] = rd.ekf_q[k]; cv.r[k] = rd.ekf_r[k]; }
+                    double T = s[VSMPC_PS_EST + 2 * lane], Td = s[VSMPC_PS_EST + 2 * lane + 1];
+                    double Pm[4] = {s[VSMPC_PS_EKFP + 4 * lane], s[VSMPC_PS_EKFP + 4 * lane + 1],
+                                    s[VSMPC_PS_EKFP + 4 * lane + 2], s[VSMPC_PS_EKFP + 4 * lane + 3]};
+                    ekf_update_dev(T, Td, Pm, s[VSMPC_PS_U + lane], double(Tn_mine), double(Tdn_mine), h, cv);
+                    s[VSMPC_PS_EST + 2 * lane] = T;
+                    s[VSMPC_PS_EST + 2 * lane + 1] = Td;
+                    for (int k = 0; k < 4; ++k) s[VSMPC_PS_EKFP + 4 * lane + k] = Pm[k];
+                    s[VSMPC_PS_TNN + lane] = double(Tn_mine);
+                    x[12 + lane] = double(Tn_mine);
+                    x[16 + lane] = double(Tdn_mine);
+                }
+                __syncthreads();
+            }
         }
         if (lane < 20) s[lane] = x[lane];
         if (lane == 0) tick[b] = tick_before + 1;

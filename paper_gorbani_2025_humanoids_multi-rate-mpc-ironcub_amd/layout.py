@@ -60,7 +60,8 @@ FM_SIZE = 24
 
 # closed-loop rollout: plant state / parameter layouts (VSMPC_PS_* / VSMPC_PP_* in include/vsmpc.h)
 PS_P, PS_HLIN, PS_RPY, PS_HANG, PS_T, PS_TD, PS_Q, PS_U, PS_TDES, PS_TDDES = 0, 3, 6, 9, 12, 16, 20, 28, 32, 36
-PLANT_STATE = 40
+PS_TNN, PS_EST, PS_EKFP = 40, 44, 52     # jet plant option (LSTM thrust, EKF estimates (T, Tdot) x 4, covariances 2x2 x 4)
+PLANT_STATE = 68
 PP_MASS, PP_INERTIA_B, PP_AMOM0, PP_DJ, PP_QREF0, PP_PINIT, PP_RPYINIT = 0, 1, 10, 34, 226, 234, 237
 PP_DIST_F, PP_DIST_TAU, PP_DIST_T0, PP_DIST_T1, PP_TICK0 = 240, 243, 246, 247, 248
 PLANT_PARAMS = 249

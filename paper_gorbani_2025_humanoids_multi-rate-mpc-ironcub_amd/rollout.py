@@ -92,6 +92,11 @@ def make_plant(cfg: L.MPCConfig, batch: int, *, workload: str = "hover", seed0: 
         s[L.PS_U:L.PS_U + 4] = u
         s[L.PS_TDES:L.PS_TDES + 4] = T
         s[L.PS_TDDES:L.PS_TDDES + 4] = 0.0
+        # jet plant option (set_jet_plant): the NN thrust and the EKF estimates start on the plant thrust, P = 0.1 I
+        # (ironcub_mujoco_simulator.py:54-57); the polynomial jet plant ignores these fields
+        s[L.PS_TNN:L.PS_TNN + 4] = np.asarray(T, dtype=np.float32)
+        s[L.PS_EST:L.PS_EST + 8:2] = T
+        s[L.PS_EKFP:L.PS_EKFP + 16] = np.tile(0.1 * np.eye(2).reshape(-1), 4)
 
         q = params[b]
         q[L.PP_MASS] = mass
@@ -176,6 +181,16 @@ class ClosedLoopRollout:
         if state.shape != (self.batch, L.PLANT_STATE) or params.shape != (self.batch, L.PLANT_PARAMS):
             raise ValueError("state / params shape does not match the rollout batch")
         _lib.check(self.lib.vsmpc_rollout_reset(self._r, _ptr(state), _ptr(params)), "vsmpc_rollout_reset")
+
+    def set_jet_plant(self, jet_model=None, Q=None, R=None):
+        """Jet plant option (vsmpc_rollout_set_jet_plant): `jet_model` = a jet_plant.JetModelTotal (the LSTM thrust model;
+        None = back to the polynomial jet plant); Q, R = EKF covariances, default 0.1 I / 0.5 I
+        (ironcub_mujoco_simulator.py:54-56).  Call reset() afterwards."""
+        Q = np.ascontiguousarray(0.1 * np.eye(2) if Q is None else Q, dtype=np.float64)
+        R = np.ascontiguousarray(0.5 * np.eye(2) if R is None else R, dtype=np.float64)
+        self._jet_model = jet_model            # keeps the jet handle alive as long as the rollout uses it
+        _lib.check(self.lib.vsmpc_rollout_set_jet_plant(self._r, None if jet_model is None else jet_model._h, _ptr(Q), _ptr(R)),
+                   "vsmpc_rollout_set_jet_plant")
 
     def run(self, ticks: int, log: bool = True, stream=None):
         """Advances every instance by `ticks` MPC periods.  Returns the log [ticks, batch, ROLLOUT_LOG] or None."""

@@ -79,8 +79,21 @@ def build_record(cfg, model, s, p):
     return tick_model.record_from_tick(cfg, model.update(s), kin_record(cfg, s, p))
 
 
-def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5):
-    """Returns the plant state after one tick (first move applied only if status == 1)."""
+def measured(s, jet=None):
+    """Plant state as the controller sees it: with the jet plant option the thrusts and thrust rates are the EKF estimates."""
+    if jet is None:
+        return s
+    m = s.copy()
+    m[L.PS_T:L.PS_T + 4] = s[L.PS_EST:L.PS_EST + 8:2]
+    m[L.PS_TD:L.PS_TD + 4] = s[L.PS_EST + 1:L.PS_EST + 8:2]
+    return m
+
+
+def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5, jet=None):
+    """Returns the plant state after one tick (first move applied only if status == 1).  `jet` = (JetLSTM, Q, R) of
+    oracle/jet_ref.py selects the jet plant option: per sub-step the mechanical state advances with the current NN thrust,
+    then every jet's thrust is advanced by the LSTM (thrust fed back) and its EKF is updated with the NN's (T, Tdot)
+    (ironcub_mujoco_simulator.py:128-133,393-396)."""
     s = s.copy()
     if status == 1:
         s[L.PS_Q:L.PS_Q + 8] += fm[L.FM_DQ:L.FM_DQ + 8]
@@ -119,6 +132,21 @@ def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5):
             Tdb = _JET.standardizeThrustDot_u2T(x[16 + i])
             d[12 + i] = x[16 + i]
             d[16 + i] = sg * (_JET.compute_f(Tb, Tdb) + _JET.compute_g(Tb, Tdb) * vthr[i])
+        if jet is not None:
+            d[12:20] = 0.0
         x = x + h * d
+        if jet is not None:
+            import jet_ref
+            lstm, Q, Rm = jet
+            u = s[L.PS_U:L.PS_U + 4]
+            Tn, Tdn, _, _ = lstm.get_state(s[L.PS_TNN:L.PS_TNN + 4].astype(np.float32), u.astype(np.float32), np.float32(h))
+            for i in range(4):
+                est, P = jet_ref.ekf_update(s[L.PS_EST + 2 * i:L.PS_EST + 2 * i + 2], s[L.PS_EKFP + 4 * i:L.PS_EKFP + 4 * i + 4].reshape(2, 2),
+                                            float(u[i]), [float(Tn[i]), float(Tdn[i])], h, Q, Rm)
+                s[L.PS_EST + 2 * i:L.PS_EST + 2 * i + 2] = est
+                s[L.PS_EKFP + 4 * i:L.PS_EKFP + 4 * i + 4] = P.reshape(-1)
+            s[L.PS_TNN:L.PS_TNN + 4] = Tn
+            x[12:16] = Tn
+            x[16:20] = Tdn
     s[0:20] = x
     return s

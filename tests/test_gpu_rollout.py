@@ -55,6 +55,59 @@ def test_record_and_advance_kernels_match_model(ro, layout, workload):
         r.close()
 
 
+def test_jet_plant_option_matches_model(ro, layout):
+    """N4 inside N1: the rollout with the LSTM jet plant + EKF (vsmpc_rollout_set_jet_plant) against the numpy model built
+    on oracle/jet_ref.py (whose LSTM is pinned to the reference's own module, tests/golden/jet_lstm.npz): records (the
+    controller sees the EKF estimates) and plant states over six ticks, then the polynomial plant again.  float32 network
+    with a different summation order: 2e-6 relative on the state, records exact up to that."""
+    import os
+    import jet_ref
+    from conftest import ROOT
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "jet_lstm.npz"))
+    jp = importlib.import_module(PKG + ".jet_plant")
+    jm = jp.JetModelTotal(gold["w_ih"], gold["w_hh"], gold["b_ih"], gold["b_hh"], gold["fc_w"], gold["fc_b"], gold["norm"],
+                          device=0, max_series=64)
+    lstm = jet_ref.JetLSTM(gold["w_ih"], gold["w_hh"], gold["b_ih"], gold["b_hh"], gold["fc_w"], gold["fc_b"], gold["norm"])
+    Q, Rm = 0.1 * np.eye(2), 0.5 * np.eye(2)
+    B = 8
+    cfg, st, pa, (pos, vel, alpha, adt), r = _make(ro, layout, B, "montecarlo")
+    try:
+        r.set_jet_plant(jm)
+        with pytest.raises(Exception):
+            r.run(1)                                           # the option changes what the records hold: reset() first
+        r.reset(st, pa)
+        jet = (lstm, Q, Rm)
+        s_host = st.copy()
+        models = [rm.make_tick_model(cfg, rm.measured(st[b], jet), pa[b], pos, vel, alpha) for b in range(B)]
+        recs = r.next_records()
+        for tick in range(6):
+            r.run(1, log=False)
+            x, fm, status, iters = r.mpc.solve(recs)
+            after = r.state()
+            for b in range(B):
+                rec_m = rm.build_record(cfg, models[b], rm.measured(s_host[b], jet), pa[b])
+                assert relerr(recs[b], rec_m) < 2e-6, (tick, b)
+                models[b].consume(fm[b], status[b])
+                s_m = rm.advance(cfg, s_host[b], pa[b], tick, fm[b], status[b], alpha, adt, jet=jet)
+                assert relerr(after[b], s_m) < 2e-6, (tick, b)
+                # the estimate follows the NN thrust, and the NN thrust moved away from the polynomial model's
+                assert np.abs(after[b, layout.PS_EST:layout.PS_EST + 8:2] - after[b, layout.PS_TNN:layout.PS_TNN + 4]).max() < 5.0
+            recs = r.next_records()
+            s_host = after
+        assert (status == layout.STATUS_SOLVED).all()
+        r.set_jet_plant(None)                                  # back to the polynomial jet plant
+        r.reset(st, pa)
+        recs = r.next_records()
+        r.run(1, log=False)
+        _, fm, status, _ = r.mpc.solve(recs)
+        after = r.state()
+        for b in range(B):
+            assert relerr(after[b], rm.advance(cfg, st[b], pa[b], 0, fm[b], status[b], alpha, adt)) < 1e-12
+    finally:
+        r.close()
+        jm.close()
+
+
 def test_tick_state_machine_matches_reference_model(ro, layout):
     """50 ticks (two releases of the 20-tick hold at ticks 19 and 39, window pushes on the same ticks) of freshly
     configured loops on the REFERENCE's own trajectory files, with the yaw drifting through +pi (wrapped measurement
