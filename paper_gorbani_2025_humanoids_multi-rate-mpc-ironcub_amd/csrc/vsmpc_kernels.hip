@@ -147,12 +147,16 @@ struct Smem {
     static constexpr int sizeM = D::L_TILES * D::TS;
     static constexpr int NVS = D::NV + 1;            // row stride of the box-QP work arrays
     static constexpr int oSv = oR;                   // Schur complement / columns of P
-    static constexpr int oQP = oSv + D::NV * NVS;    // dual form only: K | rows 16.. of X
-    static constexpr int sizeQP = DUALQP ? D::NV * NVS + (D::NV - 16) * NVS : 0;
-    static constexpr int oU = oQP + sizeQP;          // per-wavefront partial sums of L^T z, NP each
+    // three throttle tile rows, tile aligned (the 2x horizon): dual form on a dense X assembled from tile products
+    static constexpr bool DUAL3 = !DUALQP && D::NT - 3 == D::PVT && D::NU % 16 == 0 && D::NV > 32 && D::NV <= 48;
+    static constexpr int oQP = oSv + D::NV * NVS;    // dual form: K | rows 16.. of X (DUALQP); K | X | two scratch tiles (DUAL3)
+    static constexpr int sizeQP = DUALQP ? D::NV * NVS + (D::NV - 16) * NVS : (DUAL3 ? 2 * D::NV * NVS + 2 * D::TS : 0);
+    // per-wavefront partial sums of L^T z, NP each.  The box-QP arrays are dead by then: where the dense X would not fit
+    // beside them (DUAL3) the two overlap
+    static constexpr int oU = DUAL3 ? oR : oQP + sizeQP;
     static constexpr int oX = oU + D::NWAVES * D::NP;  // P6: state trajectory
     static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
-    static constexpr int endScratch = oF + NX * D::N;
+    static constexpr int endScratch = (oF + NX * D::N > oQP + sizeQP) ? oF + NX * D::N : oQP + sizeQP;
     static_assert(endScratch <= oR + D::RING_TILES * D::TS, "P4..P6 scratch must not reach the corner tiles");
     static constexpr int total = oR + (sizeY > sizeM ? sizeY : sizeM);
     static constexpr size_t bytes = size_t(total) * sizeof(double);
@@ -821,6 +825,179 @@ VS_DEV void schur_rhs(const double* __restrict__ Lb, double* __restrict__ sSvec,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Accessors of X = L22^-1 (lower triangular, NV x NV) for the dual box QP.  Entries are re-read from LDS where they are
+// used instead of held in 2 NV registers: with the accumulator tiles live through P4 the box QP must stay small in
+// registers, or tiles get spilled for EVERY instance.
+//   XTiles  two throttle tile rows (the paper horizon): rows 0..15 are the tile X6 = inverse of the first throttle
+//           diagonal tile (formed in P3), rows 16.. are formed at the top of the box QP (sXr[a * NVS + j] = X[16 + a][j])
+//   XDense  three throttle tile rows: sXd[j * NVS + i] = X[j][i], zero above the diagonal
+// col(j, r, n) = X[j][r] restricted to the rows j < n of N; pcol(b, r, n) = P[r][b] = sum_{j < n} X[j][r] X[j][b].
+// ------------------------------------------------------------------------------------------------
+template <class D>
+struct XTiles {
+    static constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
+    static constexpr int KMAX = SMALL_SOLVE_MAX;   // largest system solved in registers (the accumulator tiles are in VGPRs here)
+    const double* X6;
+    const double* sXr;
+    VS_DEV double col(int j, int r, int n) const {
+        const double t = j < 16 ? X6[j * 17 + (r & 15)] : sXr[(j - 16) * NVS + r];
+        return (j < 16 ? r < 16 : j < n) ? t : 0.0;
+    }
+    VS_DEV double pcol(int b, int r, int n) const {
+        double p0 = 0.0, p1 = 0.0;
+        if (b < 16) {  // X[j][b] = 0 for j < 16 <= b
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                p0 = fma(col(j, r, n), X6[j * 17 + b], p0);            // uniform addresses: LDS broadcasts
+                p1 = fma(col(j + 1, r, n), X6[(j + 1) * 17 + b], p1);
+            }
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < NR2; ++a2) p0 = fma(col(16 + a2, r, n), sXr[a2 * NVS + b], p0);
+        return p0 + p1;
+    }
+};
+template <class D>
+struct XDense {
+    static constexpr int NVS = D::NV + 1;
+    static constexpr int KMAX = 10;                // accumulator tiles live in AGPRs at these horizons: room for 10 x 10
+    const double* sXd;
+    VS_DEV double col(int j, int r, int n) const { return j < n ? sXd[j * NVS + r] : 0.0; }
+    VS_DEV double pcol(int b, int r, int n) const {
+        double p0 = 0.0, p1 = 0.0;
+        int j = b;                                   // X[j][b] = 0 for j < b
+        for (; j + 1 < n; j += 2) {
+            p0 = fma(sXd[j * NVS + r], sXd[j * NVS + b], p0);
+            p1 = fma(sXd[(j + 1) * NVS + r], sXd[(j + 1) * NVS + b], p1);
+        }
+        if (j < n) p0 = fma(sXd[j * NVS + r], sXd[j * NVS + b], p0);
+        return p0 + p1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Dual active-set iteration of the box QP by ONE wavefront (lane = throttle).  With N = the throttles that are not
+// pinned by the hold, P = S_NN^-1 = X^T X and v_u = the sweep's solution (sZ), fixing the set A at its bounds b_A gives
+// mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.  Only the columns of P some active set needs
+// are ever formed; the |A| x |A| system is tiny for the usual one to three saturated throttles.  The sequence of active
+// sets is exactly the block-pivoting sequence of the primal form.  sSvec[0] = max |s| (release tolerance).
+// ------------------------------------------------------------------------------------------------
+template <class D, class XA>
+VS_DEV void dual_active_set(const XA& xa, bool hold, int lane, double* __restrict__ sSv, double* __restrict__ sQP,
+                            const double* __restrict__ sSvec, const double* __restrict__ sVprev,
+                            const double* __restrict__ sCfg, double* __restrict__ sZ, int* __restrict__ sFlags) {
+    constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
+    double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
+    double* sK = sQP;                       // working copy of P_AA
+    const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
+    const bool valid = lane < D::NV;
+    const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
+    const int n = hold ? D::NV - 4 : D::NV;
+    const bool inN = valid && r < n;
+    const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
+    const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
+    const double gtol = 1e-10 * (1.0 + sSvec[0]);   // sSvec[0] = max |s| (see above)
+    const double vu = sZ[D::NU + r];
+    // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
+    // backward sweep that just ran.  Apply its flips here; nothing is at a bound yet, so only primal
+    // violations can occur.
+    int state = 0;  // 0 free, -1 at lower, +1 at upper (pinned throttles are outside N altogether)
+    double v = vu;
+    int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
+    {
+        const double tolv = 1e-12 * (1.0 + fabs(v));
+        const bool vlo = inN && (v < lo - tolv);
+        const bool vhi = inN && (v > hi + tolv);
+        best = __popcll(__ballot(vlo || vhi));
+        if (vlo || vhi) state = vlo ? -1 : 1;
+    }
+    unsigned long long have = 0ull;
+    for (int it = 1; it < AS_MAX_ITER; ++it) {
+        iters = it + 1;
+        const bool isA = inN && state != 0;
+        const unsigned long long Amask = __ballot(isA);
+        // columns of P for the newly active throttles: P[i][b] = sum_{j < n} X[j][i] X[j][b]
+        unsigned long long need = Amask & ~have;
+        have |= need;
+        while (need) {
+            const int b = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const double pb = xa.pcol(b, r, n);
+            if (valid) sP[b * NVS + r] = pb;
+        }
+        double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
+        double mu = 0.0;
+        const int ka = __popcll(Amask);
+        if (ka == 0) {
+            // every bound was released again: v = v_u, no multipliers
+        } else if (ka <= XA::KMAX) {
+            // few active bounds: solved redundantly in every lane on wave-uniform values
+            mu = small_spd_solve_n<D::NV + 1, XA::KMAX>(ka, sP, Amask, bb, lane, bad);
+        } else {
+            // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
+            if (isA) {
+                unsigned long long m = Amask;
+                while (m) {
+                    const int c = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    sK[r * NVS + c] = sP[c * NVS + r];
+                }
+            }
+            for (unsigned long long pm = Amask; pm; pm &= pm - 1) {
+                const int j = __ffsll((long long)pm) - 1;
+                const double piv = sK[j * NVS + j];
+                bad |= !(piv > 0.0);
+                const double bj = readlane_f64(bb, j);
+                if (isA && lane > j) {
+                    const double f = sK[r * NVS + j] * fast_rcp(piv);
+                    bb -= f * bj;
+                    for (unsigned long long m = pm & (pm - 1); m; m &= m - 1) {
+                        const int c = __ffsll((long long)m) - 1;
+                        sK[r * NVS + c] -= f * sK[j * NVS + c];
+                    }
+                }
+            }
+            for (unsigned long long pm = Amask; pm;) {
+                const int j = 63 - __clzll((long long)pm);
+                pm &= ~(1ull << j);
+                const double xj = readlane_f64(bb, j) * fast_rcp(sK[j * NVS + j]);
+                if (lane == j) mu = xj;
+                if (isA && lane < j) bb -= sK[r * NVS + j] * xj;
+            }
+        }
+        if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
+        // v_N = v_u,N - P[:,A] mu
+        v = vu;
+        for (unsigned long long m = Amask; m; m &= m - 1) {
+            const int b = __ffsll((long long)m) - 1;
+            const double mub = readlane_f64(mu, b);
+            if (inN) v -= sP[b * NVS + r] * mub;
+        }
+        const double grad = -mu;  // gradient of the QP at the throttles that sit on a bound
+        const double tolv = 1e-12 * (1.0 + fabs(v));
+        const bool isF = inN && state == 0;
+        const bool vlo = isF && (v < lo - tolv);
+        const bool vhi = isF && (v > hi + tolv);
+        const bool rlo = isA && state == -1 && grad < -gtol;
+        const bool rhi = isA && state == 1 && grad > gtol;
+        const bool inf = vlo || vhi || rlo || rhi;
+        const unsigned long long imask = __ballot(inf);
+        const int ninf = __popcll(imask);
+        if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
+        bool pick = inf;
+        if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
+        else if (patience > 0) { --patience; }
+        else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
+        if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
+    }
+    if (valid) {
+        v = fixed ? lo : (state < 0 ? lo : (state > 0 ? hi : v));  // bound variables sit exactly on their bound
+        sZ[D::NU + lane] = v;
+    }
+    if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // P4b: box QP on the throttles (constraintsVSMPC.cpp:338-365), entered only by instances whose pins-only solution violates
 // a bound.  Kept small in registers (K x K systems up to 6 x 6 in registers, columns of X re-read from LDS): the
 // accumulator tiles are live across it, and what it cannot hold gets spilled for every instance.  (Out of line as a
@@ -847,9 +1024,13 @@ VS_DEV void box_qp(int n_violated, bool hold) {
     constexpr bool DUALQP = S::DUALQP;
     constexpr int PV = D::PVT;
     constexpr int DUAL_MAX_ACTIVE = 10;
-    const bool use_dual = DUALQP && n_violated <= DUAL_MAX_ACTIVE;
+    constexpr bool DUAL3 = S::DUAL3;
+#ifndef VS_DUAL3_MAX
+#define VS_DUAL3_MAX 16
+#endif
+    const bool few = n_violated <= (DUAL3 ? VS_DUAL3_MAX : DUAL_MAX_ACTIVE);   // few saturated throttles: dual form
     (void)sQP; (void)sXinv; (void)sInvD;
-      if (use_dual) {
+      if (few && DUALQP) {
        if constexpr (DUALQP) {
         // ---- box QP on the throttles, dual form.  With N = the throttles that are not pinned by the hold, P = S_NN^-1
         // (S = L22 L22^T, so the factor of S_NN is the leading block of L22) and v_u = the sweep's solution, fixing the
@@ -909,134 +1090,95 @@ VS_DEV void box_qp(int n_violated, bool hold) {
         }
         if (wave == 0) {
             static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
-            constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
-            constexpr int NR2 = D::NV - 16;         // throttle rows in the second tile row
-            double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
-            double* sK = sQP;                       // working copy of P_AA
-            double* sXr = sQP + D::NV * NVS;        // rows 16.. of X: sXr[a * NVS + j] = X[16 + a][j]
-            const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
-            const bool valid = lane < D::NV;
-            const bool fixed = valid && hold && (r >= D::NV - 4);  // v0 is the trailing block
-            const int n = hold ? D::NV - 4 : D::NV;
-            const bool inN = valid && r < n;
-            const double lo = fixed ? sVprev[r & 3] : sCfg[CFG_VMIN];    // constraintsVSMPC.cpp:351-364
-            const double hi = fixed ? sVprev[r & 3] : sCfg[CFG_VMAX];
-            const double* X6 = sXinv + PV * D::TS;  // X[i][j], i, j < 16, at i*17 + j; rows 16.. are in sXr (sweep_tile)
-            const double gtol = 1e-10 * (1.0 + sSvec[0]);   // sSvec[0] = max |s| (see above)
-            const double vu = sZ[D::NU + r];
-            // Iteration 1 of the block-pivoting scheme is the solve with only the hold pin enforced: that is the
-            // backward sweep that just ran.  Apply its flips here; nothing is at a bound yet, so only primal
-            // violations can occur.
-            int state = 0;  // 0 free, -1 at lower, +1 at upper (pinned throttles are outside N altogether)
-            double v = vu;
-            int best, patience = AS_PATIENCE, status = VSMPC_STATUS_MAX_ITER, iters = 1, bad = 0;
-            {
-                const double tolv = 1e-12 * (1.0 + fabs(v));
-                const bool vlo = inN && (v < lo - tolv);
-                const bool vhi = inN && (v > hi + tolv);
-                best = __popcll(__ballot(vlo || vhi));
-                if (vlo || vhi) state = vlo ? -1 : 1;
+            const XTiles<D> xa{sXinv + PV * D::TS, sQP + D::NV * (D::NV + 1)};   // rows 16.. of X behind the copy of P_AA
+            dual_active_set<D>(xa, hold, lane, sSv, sQP, sSvec, sVprev, sCfg, sZ, sFlags);
+        }
+       }
+      } else if (few && DUAL3) {
+       if constexpr (DUAL3) {
+        // ---- dual form, three throttle tile rows: X = L22^-1 assembled dense in LDS from tile products,
+        //   X_ii = L_ii^-1 (the first one from P3, the other two here),  X10 = -X1 (L10 X0),  X21 = -X2 (L21 X1),
+        //   X20 = -X2 (L20 X0 + L21 X10);  one 16x16 entry per thread and product, four barrier-separated rounds.
+        constexpr int NVS = D::NV + 1, R2 = D::NV - 32;        // throttle rows in the last tile row
+        double* sXd = sQP + D::NV * NVS;                        // sXd[j * NVS + i] = X[j][i]
+        double* sT0 = sXd + D::NV * NVS;                        // L10 X0, later L20 X0 + L21 X10
+        double* sT1 = sT0 + D::TS;                              // L21 X1 (both tile-sized: the inverses pass through them)
+        const double* L10 = Lb + tile_off<D>(PV + 1, PV);
+        const double* L20 = Lb + tile_off<D>(PV + 2, PV);
+        const double* L21 = Lb + tile_off<D>(PV + 2, PV + 1);
+        const double* X0 = sXinv + PV * D::TS;                  // from P3
+        const int ti = tid >> 4, tj = tid & 15;                 // entry (ti, tj) of a 16 x 16 product
+        auto xd = [&](int blk_r, int blk_c) { return sXd + (16 * blk_r) * NVS + 16 * blk_c; };   // block of X, row stride NVS
+        for (int e = tid; e < D::NV * NVS; e += D::BLOCK) sXd[e] = 0.0;
+        if (tid < D::NV) {   // s = L22 (L^-1 g)_v: its largest entry scales the release tolerance
+            double sum = 0.0;
+            for (int k = 0; k <= tid; ++k)
+                sum += Lb[lower_at<D>(D::NU + tid, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
+            sSvec[tid] = sum;
+        }
+        __syncthreads();
+        // round 1: diagonal blocks (wavefronts 1, 2 invert; wavefront 0 copies X0; wavefront 3 forms max |s|), T10 later
+        if (wave == 1) {
+            tile_inverse<D>(Lb + tile_off<D>(PV + 1, PV + 1), sInvD + D::NU + 16, sT0, lane);     // into a tile-shaped scratch
+        } else if (wave == 2) {
+            tile_inverse<D>(Lb + tile_off<D>(PV + 2, PV + 2), sInvD + D::NU + 32, sT1, lane);
+        } else if (wave == 3) {
+            double gm = 0.0;
+            for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
+            if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
+        }
+        __syncthreads();
+        {   // copy the three diagonal blocks into the dense X (lower triangles; rows of the last block beyond R2 stay zero)
+            const double x0 = X0[ti * 17 + tj], x1 = sT0[ti * 17 + tj], x2 = sT1[ti * 17 + tj];
+            if (tj <= ti) {
+                xd(0, 0)[ti * NVS + tj] = x0;
+                xd(1, 1)[ti * NVS + tj] = x1;
+                if (ti < R2) xd(2, 2)[ti * NVS + tj] = x2;
             }
-            // column r of X restricted to the rows of N (this lane's factor of every P entry it forms): re-read from LDS
-            // where it is used (lane-contiguous addresses) instead of held in 2 NV registers -- with the accumulator
-            // tiles live through P4 the box QP must stay small in registers, or tiles get spilled for EVERY instance
-            auto xc = [&](int j) -> double {
-                const double t = j < 16 ? X6[j * 17 + (r & 15)] : sXr[(j - 16) * NVS + r];
-                return (j < 16 ? r < 16 : j < n) ? t : 0.0;
-            };
-            unsigned long long have = 0ull;
-            for (int it = 1; it < AS_MAX_ITER; ++it) {
-                iters = it + 1;
-                const bool isA = inN && state != 0;
-                const unsigned long long Amask = __ballot(isA);
-                // columns of P for the newly active throttles: P[i][b] = sum_{j < n} X[j][i] X[j][b]
-                unsigned long long need = Amask & ~have;
-                have |= need;
-                while (need) {
-                    const int b = __ffsll((long long)need) - 1;
-                    need &= need - 1;
-                    double p0 = 0.0, p1 = 0.0;
-                    if (b < 16) {  // X[j][b] = 0 for j < 16 <= b
+        }
+        __syncthreads();
+        {   // round 2: T10 = L10 X0, T21 = L21 X1
+            double a = 0.0, b = 0.0;
 #pragma unroll
-                        for (int j = 0; j < 16; j += 2) {
-                            p0 = fma(xc(j), X6[j * 17 + b], p0);            // uniform addresses: LDS broadcasts
-                            p1 = fma(xc(j + 1), X6[(j + 1) * 17 + b], p1);
-                        }
-                    }
+            for (int k = 0; k < 16; ++k) {
+                a = fma(L10[ti * 17 + k], xd(0, 0)[k * NVS + tj], a);
+                b = fma(L21[ti * 17 + k], xd(1, 1)[k * NVS + tj], b);
+            }
+            sT0[ti * 16 + tj] = a;
+            sT1[ti * 16 + tj] = b;
+        }
+        __syncthreads();
+        {   // round 3: X10 = -X1 T10, X21 = -X2 T21
+            double a = 0.0, b = 0.0;
 #pragma unroll
-                    for (int a2 = 0; a2 < NR2; ++a2) p0 = fma(xc(16 + a2), sXr[a2 * NVS + b], p0);
-                    if (valid) sP[b * NVS + r] = p0 + p1;
-                }
-                double bb = isA ? vu - (state < 0 ? lo : hi) : 0.0;  // right-hand side v_u,A - b_A
-                double mu = 0.0;
-                const int ka = __popcll(Amask);
-                if (ka == 0) {
-                    // every bound was released again: v = v_u, no multipliers
-                } else if (ka <= SMALL_SOLVE_MAX) {
-                    // few active bounds: solved redundantly in every lane on wave-uniform values
-                    mu = small_spd_solve_n<D::NV + 1>(ka, sP, Amask, bb, lane, bad);
-                } else {
-                    // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
-                    if (isA) {
-                        unsigned long long m = Amask;
-                        while (m) {
-                            const int c = __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            sK[r * NVS + c] = sP[c * NVS + r];
-                        }
-                    }
-                    for (unsigned long long pm = Amask; pm; pm &= pm - 1) {
-                        const int j = __ffsll((long long)pm) - 1;
-                        const double piv = sK[j * NVS + j];
-                        bad |= !(piv > 0.0);
-                        const double bj = readlane_f64(bb, j);
-                        if (isA && lane > j) {
-                            const double f = sK[r * NVS + j] * fast_rcp(piv);
-                            bb -= f * bj;
-                            for (unsigned long long m = pm & (pm - 1); m; m &= m - 1) {
-                                const int c = __ffsll((long long)m) - 1;
-                                sK[r * NVS + c] -= f * sK[j * NVS + c];
-                            }
-                        }
-                    }
-                    for (unsigned long long pm = Amask; pm;) {
-                        const int j = 63 - __clzll((long long)pm);
-                        pm &= ~(1ull << j);
-                        const double xj = readlane_f64(bb, j) * fast_rcp(sK[j * NVS + j]);
-                        if (lane == j) mu = xj;
-                        if (isA && lane < j) bb -= sK[r * NVS + j] * xj;
-                    }
-                }
-                if (bad) { status = VSMPC_STATUS_NUMERICAL; break; }
-                // v_N = v_u,N - P[:,A] mu
-                v = vu;
-                for (unsigned long long m = Amask; m; m &= m - 1) {
-                    const int b = __ffsll((long long)m) - 1;
-                    const double mub = readlane_f64(mu, b);
-                    if (inN) v -= sP[b * NVS + r] * mub;
-                }
-                const double grad = -mu;  // gradient of the QP at the throttles that sit on a bound
-                const double tolv = 1e-12 * (1.0 + fabs(v));
-                const bool isF = inN && state == 0;
-                const bool vlo = isF && (v < lo - tolv);
-                const bool vhi = isF && (v > hi + tolv);
-                const bool rlo = isA && state == -1 && grad < -gtol;
-                const bool rhi = isA && state == 1 && grad > gtol;
-                const bool inf = vlo || vhi || rlo || rhi;
-                const unsigned long long imask = __ballot(inf);
-                const int ninf = __popcll(imask);
-                if (ninf == 0) { status = VSMPC_STATUS_SOLVED; break; }
-                bool pick = inf;
-                if (ninf < best) { best = ninf; patience = AS_PATIENCE; }
-                else if (patience > 0) { --patience; }
-                else { pick = inf && (lane == 63 - __clzll(imask)); }  // least-index fallback (largest index)
-                if (pick) state = vlo ? -1 : (vhi ? 1 : 0);
+            for (int k = 0; k < 16; ++k) a = fma(xd(1, 1)[ti * NVS + k], sT0[k * 16 + tj], a);
+            const int t2 = ti < R2 ? ti : 0;                    // X2 is R2 x R2: rows / columns beyond it do not exist
+#pragma unroll
+            for (int k = 0; k < R2; ++k) b = fma(xd(2, 2)[t2 * NVS + k], sT1[k * 16 + tj], b);
+            xd(1, 0)[ti * NVS + tj] = -a;
+            if (ti < R2) xd(2, 1)[ti * NVS + tj] = -b;
+        }
+        __syncthreads();
+        {   // round 4: T20 = L20 X0 + L21 X10
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                a = fma(L20[ti * 17 + k], xd(0, 0)[k * NVS + tj], a);
+                a = fma(L21[ti * 17 + k], xd(1, 0)[k * NVS + tj], a);
             }
-            if (valid) {
-                v = fixed ? lo : (state < 0 ? lo : (state > 0 ? hi : v));  // bound variables sit exactly on their bound
-                sZ[D::NU + lane] = v;
-            }
-            if (lane == 0) { sFlags[1] = status; sFlags[2] = iters; }
+            sT0[ti * 16 + tj] = a;
+        }
+        __syncthreads();
+        {   // round 5: X20 = -X2 T20
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < R2; ++k) a = fma(xd(2, 2)[(ti < R2 ? ti : 0) * NVS + k], sT0[k * 16 + tj], a);
+            if (ti < R2) xd(2, 0)[ti * NVS + tj] = -a;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const XDense<D> xa{sXd};
+            dual_active_set<D>(xa, hold, lane, sSv, sQP, sSvec, sVprev, sCfg, sZ, sFlags);
         }
        }
       } else {
