@@ -5,7 +5,12 @@ is the MONODROMY matrix over one hold period: finite differences of the 20-tick 
     s -> advance(s, first_move(oracle(record(s))))
 about the hover equilibrium of one instance (reference window at rest, no bound active near hover), over the plant
 state (p, h_lin, rpy, h_ang, T, Tdot, q, u, T_des, Tdot_des).  `spectral_radius()` is what the GPU property test
-derives its decay bound from (tests/test_gpu_rollout.py) instead of fitting a threshold to the run."""
+derives its decay bound from (tests/test_gpu_rollout.py) instead of fitting a threshold to the run.
+
+The full derivation costs ~2,200 oracle solves (minutes), so its result is committed as a fixture:
+    python tests/closed_loop_linearisation.py --write     ->  tests/golden/hover_monodromy.npz  (M, orbit point, rho)
+tests/test_closed_loop_linearisation.py re-derives the orbit residual and two columns from scratch on every CPU run and
+compares them with the fixture; the GPU test loads the fixture."""
 from __future__ import annotations
 
 import importlib
@@ -50,19 +55,52 @@ def monodromy(seed0=4321, eps=1e-6):
     s = st[0].copy()
     for _ in range(30):
         s = period_map(cfg, rcfg, ref, rm, s, p, traj)
-    n = layout.PLANT_STATE
+    n = N_LIN
     f0 = period_map(cfg, rcfg, ref, rm, s, p, traj)
     M = np.zeros((n, n))
-    scale = np.ones(n)
+    scale = fd_scale(layout)
+    for i in range(n):
+        M[:, i] = column(cfg, rcfg, ref, rm, s, p, traj, i, eps * scale[i])
+    return M, s, f0
+
+
+N_LIN = 40   # plant state proper (p, h_lin, rpy, h_ang, T, Tdot, q, u, T_des, Tdot_des); the fields of the jet plant option
+             # behind it are not touched by the polynomial jet plant
+
+
+def fd_scale(layout):
+    scale = np.ones(N_LIN)
     scale[layout.PS_T:layout.PS_T + 4] = 10.0
     scale[layout.PS_TD:layout.PS_TD + 4] = 10.0
     scale[layout.PS_U:layout.PS_U + 4] = 1.0
     scale[layout.PS_TDES:layout.PS_TDES + 8] = 10.0
-    for i in range(n):
-        d = np.zeros(n)
-        d[i] = eps * scale[i]
-        M[:, i] = (period_map(cfg, rcfg, ref, rm, s + d, p, traj) - period_map(cfg, rcfg, ref, rm, s - d, p, traj)) / (2 * d[i])
-    return M, s, f0
+    return scale
+
+
+def column(cfg, rcfg, ref, rm, s, p, traj, i, step):
+    """Column i of the monodromy matrix by central differences about the orbit point `s`."""
+    d = np.zeros(len(s))
+    d[i] = step
+    return ((period_map(cfg, rcfg, ref, rm, s + d, p, traj) - period_map(cfg, rcfg, ref, rm, s - d, p, traj)) / (2 * step))[:N_LIN]
+
+
+def setup(seed0=4321):
+    """(cfg, rcfg, ref, rm, layout, p, traj) of the instance the linearisation is taken about."""
+    import rollout_model as rm
+    import vsmpc_ref as ref
+    layout = importlib.import_module(PKG + ".layout")
+    ro = importlib.import_module(PKG + ".rollout")
+    cfg, rcfg = layout.paper_config(), ref.paper_config()
+    st, pa = ro.make_plant(cfg, 1, workload="hover", seed0=seed0)
+    return cfg, rcfg, ref, rm, layout, st[0].copy(), pa[0].copy(), ro.make_trajectory(cfg, "hover", 5.0)
+
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "hover_monodromy.npz")
+
+
+def load_fixture():
+    d = np.load(FIXTURE)
+    return d["M"], d["orbit"], float(d["rho"])
 
 
 def spectral_radius(M):
@@ -77,3 +115,6 @@ if __name__ == "__main__":
     print("residual of the orbit:", np.abs(f0 - s).max())
     print("spectral radius per hold period (0.1 s):", np.abs(ev).max(), " time %.0f s" % (time.time() - t))
     print(np.sort(np.abs(ev))[::-1][:10])
+    if "--write" in sys.argv:
+        np.savez(FIXTURE, M=M, orbit=s, rho=np.abs(ev).max(), seed0=4321, eps=1e-6)
+        print("wrote", FIXTURE)
