@@ -256,8 +256,9 @@ int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state);
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
 
 /* Pinned host memory for the caller's in/x/first_move/status buffers (thin wrappers of hipHostMalloc / hipHostFree,
- * so that a C caller need not link the HIP runtime): with pinned buffers vsmpc_solve_batch overlaps upload, solve and
- * download chunk by chunk.  Returns NULL on failure. */
+ * so that a C caller need not link the HIP runtime).  With pinned OUTPUT buffers vsmpc_solve_batch lets the kernel write
+ * the results straight into them (no device-to-host copies) while the uploads of the next chunk overlap the solves of
+ * the current one; with pageable buffers the runtime stages the copies itself.  Returns NULL on failure. */
 void* vsmpc_alloc_host(size_t bytes);
 void vsmpc_free_host(void* p);
 
