@@ -405,8 +405,8 @@ VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __re
 // P3 panel factorisation by ONE wavefront, branch-free: lane l owns panel rows 16p + 64 s + l for the row slots
 // s = 0..NSLOT-1 (slot 0, lanes 0..15 = the diagonal tile).  Pivot-column entries are broadcast with v_readlane;
 // each broadcast feeds the updates of all slots.  NPIV < 16 only for the last panel, whose remaining rows
-// (gradient row, padding) are carried along as ordinary panel rows.  `Lb` is the tile storage of the factor
-// (LDS for the paper horizon, a global workspace for horizons whose factor does not fit LDS).
+// (gradient row, padding) are carried along as ordinary panel rows.  `Lb` is the LDS tile storage of the panel
+// column (ring of two columns + throttle corner, tile_off_c).
 // Returns non-zero if a pivot was not positive.
 // ------------------------------------------------------------------------------------------------
 // SPLIT: the panel is shared by several wavefronts with no communication.  Each takes the diagonal tile in lanes
