@@ -108,6 +108,37 @@ def test_jet_plant_option_matches_model(ro, layout):
         jm.close()
 
 
+def test_jet_plant_option_closed_loop_properties(ro, layout):
+    """256 hover loops, 2 s, with the LSTM jet plant + EKF in the loop (the controller's own jet model is the polynomial
+    one, so this is a loop with model mismatch): every solve optimal, the EKF estimates stay on the NN thrust, the
+    thrusts stay in the model's range, the altitude stays near the reference."""
+    import os
+    from conftest import ROOT
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "jet_lstm.npz"))
+    jp = importlib.import_module(PKG + ".jet_plant")
+    jm = jp.JetModelTotal(gold["w_ih"], gold["w_hh"], gold["b_ih"], gold["b_hh"], gold["fc_w"], gold["fc_b"], gold["norm"],
+                          device=0, max_series=64)
+    B, T = 256, 400
+    cfg, st, pa, _, r = _make(ro, layout, B, "hover")
+    try:
+        r.set_jet_plant(jm)
+        r.reset(st, pa)
+        log = r.run(T)
+        final = r.state()
+    finally:
+        r.close()
+        jm.close()
+    assert (log[:, :, 14] == 1).all()
+    est = final[:, layout.PS_EST:layout.PS_EST + 8:2]
+    tnn = final[:, layout.PS_TNN:layout.PS_TNN + 4]
+    assert np.abs(est - tnn).max() < 2.0                       # N: the estimate follows the plant thrust
+    assert (tnn > 50).all() and (tnn < 260).all()
+    np.testing.assert_array_equal(final[:, layout.PS_T:layout.PS_T + 4], tnn)
+    z_err = np.abs(log[-50:, :, 2] - pa[None, :, layout.PP_PINIT + 2])
+    assert np.median(z_err) < 0.1 and z_err.max() < 0.6
+    assert np.isfinite(final).all()
+
+
 def test_tick_state_machine_matches_reference_model(ro, layout):
     """50 ticks (two releases of the 20-tick hold at ticks 19 and 39, window pushes on the same ticks) of freshly
     configured loops on the REFERENCE's own trajectory files, with the yaw drifting through +pi (wrapped measurement

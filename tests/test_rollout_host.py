@@ -118,3 +118,33 @@ def test_tick_model_follows_the_reference_call_counts(layout):
         assert np.abs(f["rpy"]).max() <= np.pi
     assert m.init_state.m_nTurns[2] == 1                      # one turn counted at the crossing
     assert m.cost.m_trajManager.trajectoryIndex == 1 + 4245 // 20
+
+
+def test_model_jet_stage_is_the_oracle_plant_run():
+    """The jet plant option of the rollout's numpy model (rollout_model.advance(jet=...)) advances thrust and estimates
+    exactly like oracle/jet_ref.plant_run (the restatement of ironcub_mujoco_simulator.py:128-133,393-396) over the
+    five 1 ms sub-steps of a tick with the throttle held."""
+    import os
+    import jet_ref
+    import rollout_model as rm
+    from conftest import PKG, ROOT
+    import importlib
+    L = importlib.import_module(PKG + ".layout")
+    ro = importlib.import_module(PKG + ".rollout")
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "jet_lstm.npz"))
+    lstm = jet_ref.JetLSTM(gold["w_ih"], gold["w_hh"], gold["b_ih"], gold["b_hh"], gold["fc_w"], gold["fc_b"], gold["norm"])
+    Q, R = 0.1 * np.eye(2), 0.5 * np.eye(2)
+    cfg = L.paper_config()
+    st, pa = ro.make_plant(cfg, 3, workload="montecarlo")
+    pos, vel, alpha, adt = ro.make_trajectory(cfg, "hover", 5.0)
+    for b in range(3):
+        s = st[b].copy()
+        s[L.PS_U:L.PS_U + 4] = s[L.PS_U:L.PS_U + 4].astype(np.float32)   # plant_run keeps the throttle in float32
+        after = rm.advance(cfg, s, pa[b], 0, np.zeros(L.FM_SIZE), 0, alpha, adt, jet=(lstm, Q, R))   # status 0: nothing consumed
+        Tn, est, P, _ = jet_ref.plant_run(lstm, s[L.PS_TNN:L.PS_TNN + 4], s[L.PS_EST:L.PS_EST + 8].reshape(4, 2),
+                                          s[L.PS_EKFP:L.PS_EKFP + 16].reshape(4, 2, 2), s[L.PS_U:L.PS_U + 4], 5,
+                                          cfg.period_mpc / 5, Q, R)
+        np.testing.assert_array_equal(after[L.PS_TNN:L.PS_TNN + 4], Tn.astype(np.float64))
+        np.testing.assert_allclose(after[L.PS_EST:L.PS_EST + 8], est.reshape(-1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(after[L.PS_EKFP:L.PS_EKFP + 16], P.reshape(-1), rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(after[L.PS_T:L.PS_T + 4], after[L.PS_TNN:L.PS_TNN + 4])      # the forces see the NN thrust
