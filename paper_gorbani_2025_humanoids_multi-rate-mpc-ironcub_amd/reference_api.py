@@ -281,8 +281,11 @@ class VariableSamplingMPC:
         k[L.KIN_ARMS:L.KIN_ARMS + 12] = np.asarray(robot.getMatrixOfJetArms(), float).reshape(-1)       # 4 x 3
         jrel = robot.getRelativeJacobianJetsBodyFrame()                                                  # 4 x (6 x 23)
         k[L.KIN_JREL:L.KIN_JREL + 276] = np.stack([np.asarray(j, float)[3:6, :] for j in jrel]).reshape(-1)
-        k[L.KIN_JFRAME:L.KIN_JFRAME + 276] = np.stack([np.asarray(robot.getJacobianJet(i), float)[0:3, 6:29]
-                                                       for i in range(4)]).reshape(-1)
+        if hasattr(robot, "getJetsList") and hasattr(robot, "getJacobian"):        # the reference's Robot (systemDynamicsVSMPC.cpp:167,208-212)
+            jac = [robot.getJacobian(name) for name in robot.getJetsList()]
+        else:                                                                        # index-based providers (tests, synthetic robots)
+            jac = [robot.getJacobianJet(i) for i in range(4)]
+        k[L.KIN_JFRAME:L.KIN_JFRAME + 276] = np.stack([np.asarray(j, float)[0:3, 6:29] for j in jac]).reshape(-1)
         k[L.KIN_JCOM:L.KIN_JCOM + 69] = np.asarray(robot.getJacobianCoM(), float)[0:3, 6:29].reshape(-1)
         k[L.KIN_MB:L.KIN_MB + 36] = np.asarray(robot.getMassMatrix(), float)[0:6, 0:6].reshape(-1)
         k[L.KIN_R:L.KIN_R + 3] = np.asarray(robot.getPositionCoM(), float) - np.asarray(robot.getBasePosition(), float)
