@@ -11,7 +11,7 @@ objects with the Robot getters the path reads (utils/include/Robot.h; the list i
 field).  Provider protocol (names of the reference's own Python binding, flightCtrlPyBindings.cpp:66-92, where it has
 one): getPositionCoM, getMomentum(inBodyCoord), getBasePosition, getBaseOrientation (RPY) or getBaseRotation (3x3),
 getBaseAngVel, getJetThrusts, getTotalMass, getGravity, getMassMatrix, getMatrixAmomJets(inBodyCoord),
-getMatrixOfJetAxes, getMatrixOfJetArms, getRelativeJacobianJetsBodyFrame, getJacobianJet(i) (= getJacobian of jet
+getMatrixOfJetAxes, getMatrixOfJetArms, getRelativeJacobianJetsBodyFrame, getJetsList / getJacobian(frameName) (= getJacobian of jet
 frame i), getJacobianCoM, getJointPos.  `QPInput` below is such an object for callers that do not have the reference's bindings; `paramHandler` is a
 mapping with the VS_MPC_CONFIG keys of src/config/vs_mcp_config.xml:7-43 (or any object with getParameter(name)), with
 the trajectories passed as arrays under "TRAJECTORY_MANAGER" / "POSITION_TRAJECTORY" (MAT-file reading stays outside).
@@ -281,10 +281,7 @@ class VariableSamplingMPC:
         k[L.KIN_ARMS:L.KIN_ARMS + 12] = np.asarray(robot.getMatrixOfJetArms(), float).reshape(-1)       # 4 x 3
         jrel = robot.getRelativeJacobianJetsBodyFrame()                                                  # 4 x (6 x 23)
         k[L.KIN_JREL:L.KIN_JREL + 276] = np.stack([np.asarray(j, float)[3:6, :] for j in jrel]).reshape(-1)
-        if hasattr(robot, "getJetsList") and hasattr(robot, "getJacobian"):        # the reference's Robot (systemDynamicsVSMPC.cpp:167,208-212)
-            jac = [robot.getJacobian(name) for name in robot.getJetsList()]
-        else:                                                                        # index-based providers (tests, synthetic robots)
-            jac = [robot.getJacobianJet(i) for i in range(4)]
+        jac = [robot.getJacobian(name) for name in robot.getJetsList()]             # systemDynamicsVSMPC.cpp:167,208-212
         k[L.KIN_JFRAME:L.KIN_JFRAME + 276] = np.stack([np.asarray(j, float)[0:3, 6:29] for j in jac]).reshape(-1)
         k[L.KIN_JCOM:L.KIN_JCOM + 69] = np.asarray(robot.getJacobianCoM(), float)[0:3, 6:29].reshape(-1)
         k[L.KIN_MB:L.KIN_MB + 36] = np.asarray(robot.getMassMatrix(), float)[0:6, 0:6].reshape(-1)

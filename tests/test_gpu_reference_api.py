@@ -51,7 +51,8 @@ class FakeRobot:
     def getMatrixOfJetAxes(self): return self.axes
     def getMatrixOfJetArms(self): return self.arms
     def getRelativeJacobianJetsBodyFrame(self): return self.jrel
-    def getJacobianJet(self, i): return self.jframe[i]
+    def getJetsList(self): return ["l_arm_jet_turbine", "r_arm_jet_turbine", "chest_l_jet_turbine", "chest_r_jet_turbine"]
+    def getJacobian(self, frameName): return self.jframe[self.getJetsList().index(frameName)]
     def getJacobianCoM(self): return self.jcom
     def getJointPos(self): return self.q
 
