@@ -54,14 +54,12 @@ def cpu_baseline(cfg_name: str, inputs: np.ndarray, budget_s: float = 15.0):
 
 
 def kernel_form(mpc, batch, dev):
-    """Which form of the solve kernel a launch of `batch` instances takes (include/vsmpc.h, vsmpc_set_kernel_form)."""
-    import torch
-    forced = os.environ.get("VSMPC_FORM", "")[:1]
-    two_forms = mpc.n_p <= 128          # horizons whose wavefronts fit 256 registers
-    cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    latency = two_forms and (forced == "l" or (forced != "t" and batch <= cus))
-    return ("latency: 8 wavefronts, one workgroup per CU" if latency
-            else ("throughput: 4 wavefronts, two workgroups per CU" if two_forms else "4 wavefronts, one workgroup per CU"))
+    """How the solve kernel of this handle condenses the QP (include/vsmpc.h, vsmpc_set_kernel_form)."""
+    forced = os.environ.get("VSMPC_FORM", "")[:2]
+    structured = mpc.n_p <= 128 and forced != "sy"      # horizons with Dims::STRUCT_P1 default to it
+    wgs = "two workgroups per CU" if mpc.n_p <= 128 else "one workgroup per CU"
+    return (("structured condensing (forward / adjoint recursions)" if structured else "sensitivity recursion + SYRK on the matrix cores")
+            + f"; 4 wavefronts, {wgs}")
 
 
 def parity_sample(cfg_name: str, inputs: np.ndarray, x: np.ndarray, k: int = 8) -> float:

@@ -262,13 +262,14 @@ int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
 void* vsmpc_alloc_host(size_t bytes);
 void vsmpc_free_host(void* p);
 
-/* The solve kernel has two forms for horizons whose condensed dimension is <= 128 (the paper's): the THROUGHPUT form
- * (two instances share a compute unit and fill each other's stalls) and the LATENCY form (one instance per compute unit,
- * eight wavefronts, the sensitivity recursion of the next pass runs beside the matrix-core work of the current one).
- * Default (form 0): latency form when the batch leaves no compute unit with two instances, throughput form otherwise.
- * form 1 pins the throughput form, form 2 the latency form (process-wide; measurements and tests; results of the two
- * forms are bit-identical).  Returns the previous setting, or VSMPC_ERR_INVALID_ARG. */
-int vsmpc_set_kernel_form(int form);
+/* How the solve kernel condenses the QP (what constraintsVSMPC.cpp:76-131 / costsVSMPC.cpp:166-200 imply once the states
+ * are eliminated).  STRUCTURED (form 1; the default where the horizon has it: nIter <= 18, even controlHorizon): forward /
+ * adjoint recursions on 3 generator columns per joint block + the throttle columns, O(N^2) small 3x3 work.  SYRK (form 2;
+ * every horizon): the sensitivity recursion of all condensed columns + C = sum_k Y_k^T Y_k on the matrix cores.  Form 0
+ * restores the horizon's default.  The two forms agree to rounding (different summation order), not bit for bit.
+ * Per handle; a new handle starts with the default (or with VSMPC_FORM=structured|syrk from the environment).
+ * Returns the previous setting, VSMPC_ERR_INVALID_ARG, or VSMPC_ERR_UNSUPPORTED_CONFIG (form 1 without the instantiation). */
+int vsmpc_set_kernel_form(vsmpc_handle* h, int form);
 
 const char* vsmpc_strerror(int code);
 const char* vsmpc_kernel_name(const vsmpc_handle* h);

@@ -87,7 +87,7 @@ def load():
     lib.vsmpc_alloc_host.restype = vp
     lib.vsmpc_free_host.argtypes = [vp]
     lib.vsmpc_free_host.restype = None
-    lib.vsmpc_set_kernel_form.argtypes = [c_int]
+    lib.vsmpc_set_kernel_form.argtypes = [vp, c_int]
     lib.vsmpc_set_kernel_form.restype = c_int
     lib.vsmpc_rollout_set_jet_plant.argtypes = [vp, vp, dp, dp]
     lib.vsmpc_rollout_set_jet_plant.restype = c_int

@@ -17,6 +17,7 @@ struct vsmpc_handle {
     vsmpc_config cfg;
     DevCfg dev;
     int variant;
+    int form;        // condensing form of the solve kernel (vsmpc_set_kernel_form)
     int device;
     int max_batch;
     int n_var, n_con, n_in, n_p;
@@ -162,6 +163,8 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     h->cfg = *cfg;
     fill_devcfg(*cfg, h->dev);
     h->variant = variant;
+    h->form = initial_kernel_form();
+    if (h->form == 1 && !variant_has_structured(variant)) h->form = 0;
     h->device = device;
     h->max_batch = max_batch;
     const int N = cfg->n_iter, nS = cfg->n_iter_small, H = cfg->control_horizon;
@@ -239,7 +242,7 @@ int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, dou
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(launch_solve(h->variant, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
+    HIP_TRY(launch_solve(h->variant, h->form, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
                          nullptr, static_cast<hipStream_t>(stream)));
     return VSMPC_OK;
 }
@@ -265,7 +268,7 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         int* dst = reinterpret_cast<int*>(dfm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
         int* dit = dst + ZC_MAX;
         memcpy(hin, in, B * h->n_in * sizeof(double));
-        HIP_TRY(launch_solve(h->variant, h->dev, din, batch, dx, dfm, dst, dit, nullptr, nullptr, nullptr, s));
+        HIP_TRY(launch_solve(h->variant, h->form, h->dev, din, batch, dx, dfm, dst, dit, nullptr, nullptr, nullptr, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (x) memcpy(x, hx, B * h->n_var * sizeof(double));
         if (first_move) memcpy(first_move, hfm, B * VSMPC_FM_SIZE * sizeof(double));
@@ -300,12 +303,12 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
         hipStream_t ps = h->pipe[k % nstreams];
         HIP_TRY(hipMemcpyAsync(h->d_in + o * h->n_in, in + o * h->n_in, N * h->n_in * sizeof(double), hipMemcpyHostToDevice, ps));
         if (direct) {
-            HIP_TRY(launch_solve(h->variant, h->dev, h->d_in + o * h->n_in, n, x ? zx + o * h->n_var : nullptr,
+            HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in + o * h->n_in, n, x ? zx + o * h->n_var : nullptr,
                                  first_move ? zfm + o * VSMPC_FM_SIZE : nullptr, zst + o, iters ? zit + o : nullptr,
                                  nullptr, nullptr, nullptr, ps));
             continue;
         }
-        HIP_TRY(launch_solve(h->variant, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
+        HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
                              h->d_fm + o * VSMPC_FM_SIZE, h->d_status + o, h->d_iters + o, nullptr, nullptr, nullptr, ps));
         if (x) HIP_TRY(hipMemcpyAsync(x + o * h->n_var, h->d_x + o * h->n_var, N * h->n_var * sizeof(double), hipMemcpyDeviceToHost, ps));
         if (first_move)
@@ -442,7 +445,7 @@ int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, doub
     const size_t np2 = size_t(h->n_p) * h->n_p;
     HIP_TRY(hipMemcpy(h->d_in, in_one, h->n_in * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->d_dbg, 0, 2 * np2 * sizeof(double)));   // the kernel writes the lower triangles only
-    HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, 1, h->d_x, h->d_fm, h->d_status, h->d_iters, h->d_dbg,
+    HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in, 1, h->d_x, h->d_fm, h->d_status, h->d_iters, h->d_dbg,
                          h->d_dbg + np2, nullptr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     if (M) HIP_TRY(hipMemcpy(M, h->d_dbg, np2 * sizeof(double), hipMemcpyDeviceToHost));
@@ -479,7 +482,7 @@ int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsig
     HIP_TRY(hipMemset(d_st, 0, size_t(batch) * 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemcpy(h->d_in, in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice));
     for (int rep = 0; rep < 3; ++rep)  // warm instruction caches, keep the last run
-        HIP_TRY(launch_solve(h->variant, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+        HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
                              nullptr, d_st, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(stamps16, d_st, size_t(batch) * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -624,7 +627,7 @@ constexpr int GRAPH_TICKS = 25;  // ticks per captured graph (50 kernel nodes)
 // synchronisation the loop needs
 hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
     vsmpc_handle* h = r->h;
-    hipError_t e = launch_solve(h->variant, h->dev, r->d_rec, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
+    hipError_t e = launch_solve(h->variant, h->form, h->dev, r->d_rec, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
                                 nullptr, nullptr, s);
     if (e == hipSuccess)
         e = launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
@@ -699,9 +702,12 @@ int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records) {
     return VSMPC_OK;
 }
 
-int vsmpc_set_kernel_form(int form) {
-    if (form < 0 || form > 2) return VSMPC_ERR_INVALID_ARG;
-    return set_kernel_form(form);
+int vsmpc_set_kernel_form(vsmpc_handle* h, int form) {
+    if (h == nullptr || form < 0 || form > 2) return VSMPC_ERR_INVALID_ARG;
+    if (form == 1 && !variant_has_structured(h->variant)) return VSMPC_ERR_UNSUPPORTED_CONFIG;
+    const int prev = h->form;
+    h->form = form;
+    return prev;
 }
 
 void* vsmpc_alloc_host(size_t bytes) {

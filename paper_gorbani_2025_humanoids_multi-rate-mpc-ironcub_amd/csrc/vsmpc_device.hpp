@@ -67,6 +67,12 @@ struct Dims {
     static constexpr int RING_TILES = 2 * NT - 1;            // + an odd one (at most NT - 1)
     static constexpr int NCORNER = (NT - PVT) * (NT - PVT + 1) / 2;
     static constexpr int L_TILES = RING_TILES + NCORNER;     // LDS tiles addressed through tile_off()
+    // Structured condensing (kernel v13, P1s in vsmpc_kernels.hip): the condensed Hessian from forward / adjoint
+    // recursions of 3 HC generator columns + NV throttle columns + the affine column per half, whose forward
+    // trajectories (9 N doubles) stay in the registers of the lane that owns the column.  Needs the trajectory to fit
+    // the register file and the joint rows to be tile aligned; other horizons condense with the SYRK (P1).
+    static constexpr bool STRUCT_P1 = N <= 18 && NU % 16 == 0 && 3 * HC <= 64 && NV + 1 <= 64 && NP <= 128;
+    static constexpr int NJPAIR = HC * (HC + 1) / 2;         // joint block pairs (row block >= column block)
     static_assert(PVT >= 1 && PVT < NT, "throttle corner");
     static_assert(N <= MAX_STAGES, "horizon too long");
     static_assert(NV <= 64, "throttle block must fit one wavefront");

@@ -158,13 +158,35 @@ struct Smem {
     static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
     static constexpr int endScratch = (oF + NX * D::N > oQP + sizeQP) ? oF + NX * D::N : oQP + sizeQP;
     static_assert(endScratch <= oR + D::RING_TILES * D::TS, "P4..P6 scratch must not reach the corner tiles");
-    static constexpr int total = oR + (sizeY > sizeM ? sizeY : sizeM);
+    // P1a: jet thrust trajectories [NJROW][N] and the affine column's momentum forcing [2][N][3], at the head of the X
+    // region (the X tiles are not written before P3)
+    static constexpr int NJROW = D::NV + NTH + 1;
+    static constexpr int oJetT = oXinv;
+    static constexpr int oGA = oJetT + NJROW * D::N;
+    // P1s (structured condensing, Dims::STRUCT_P1): behind them, across the rest of the X region and R
+    //   sH [2][NJPAIR][3][3]      block sums of H(i, i') over (row block, column block) pairs of the joint blocks
+    //   sRb[2][NV + 1][HC][3]     W_c(i) of the throttle columns and of the affine column, summed over joint blocks
+    //   sW3[2][NV + 1][N - 1][3]  W_c(i), i = 1 .. N - 1, of the throttle columns and of the affine column
+    //   sAc[NV + 1][N - 1][4]     sum over the halves of A_mom[:, q]^T W_c(i) (formed by all wavefronts after the chains)
+    //   sRefC[NREF][12]           reference window with the integrator offsets c_e folded into the x rows
+    //   sZero                     zeros: what the columns without a thrust trajectory / forcing / reference read
+    static constexpr int oSH = oGA + 6 * D::N;
+    static constexpr int oSRb = oSH + 2 * D::NJPAIR * 9;
+    static constexpr int oSW3 = oSRb + 2 * (D::NV + 1) * D::HC * 3;
+    static constexpr int oSAc = oSW3 + 2 * (D::NV + 1) * (D::N - 1) * 3;
+    static constexpr int oSRefC = oSAc + (D::NV + 1) * (D::N - 1) * 4;
+    static constexpr int oSZero = oSRefC + 12 * D::NREF;
+    static constexpr int sizeZero = 3 * D::N > 12 * D::NREF ? 3 * D::N : 12 * D::NREF;
+    static constexpr int endP1s = oSZero + sizeZero;
+    static constexpr int total_syrk = oR + (sizeY > sizeM ? sizeY : sizeM);
+    static constexpr int total_struct = D::STRUCT_P1 ? (endP1s > oR + sizeM ? endP1s : oR + sizeM) : total_syrk;
+    // both forms share one carve-up; a horizon with the structured form never launches the SYRK form unless asked to
+    // (vsmpc_set_kernel_form), so each form gets its own size
+    static constexpr int total = total_syrk;
     static constexpr size_t bytes = size_t(total) * sizeof(double);
-    static_assert(bytes <= 160 * 1024, "LDS budget of one CU");
-    // latency form of the kernel (one workgroup per CU, see solve_kernel): a second Y buffer right behind the first
-    static constexpr int total_lat = oR + (2 * sizeY > sizeM ? 2 * sizeY : sizeM);
-    static constexpr size_t bytes_lat = size_t(total_lat) * sizeof(double);
-    static_assert(D::WG_PER_CU < 2 || bytes_lat <= 160 * 1024, "LDS budget of one CU");
+    static constexpr size_t bytes_struct = size_t(total_struct) * sizeof(double);
+    static_assert(bytes <= 160 * 1024 && bytes_struct <= 160 * 1024, "LDS budget of one CU");
+    static_assert(D::WG_PER_CU < 2 || (bytes <= 80 * 1024 && bytes_struct <= 80 * 1024), "two workgroups per CU");
 };
 
 // tile (i, j), j <= i, of the factor in LDS: panel columns left of the throttle corner live in a ring of two
@@ -1305,6 +1327,351 @@ VS_DEV void box_qp(int n_violated, bool hold) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// P1s: structured condensing (Dims::STRUCT_P1; executable model: tests/condense_model.py).
+//
+// The model (systemDynamicsVSMPC.cpp:79-103,288-319,384-429) is a cascade throttles -> jets -> momenta -> CoM / RPY ->
+// error integrators whose linear half (p, h_lin, e_pos) and angular half (rpy, h_ang, e_rpy) do not talk to each other,
+// and every input reaches a half only as a 3-vector forcing of its momentum rows:  phi_i = Lambda U_{jb(i)} + A_mom T_i.
+// Per half, with xi = (x, h, e), Abar_m = I + dt_m K, the condensed Hessian (what constraintsVSMPC.cpp:76-131 and
+// costsVSMPC.cpp:166-200 imply once the states are eliminated) is
+//     C[r, c] = sum_half sum_i pi_r(i)^T W_c(i),      W_c(i) = dt_i E_h^T nu_c(i + 1),
+//     nu_c(m) = Q xi^c_m + Abar_m^T nu_c(m + 1)       (adjoint of column c's own forward trajectory xi^c),
+// pi_c(i) the column's forcing profile: Lambda[:, q] while jb(i) = b for the joint column (b, q), A_mom[:, q] tau_i for a
+// throttle column (tau = its jet's thrust trajectory from P1a).  A joint block only ever enters through the three momentum
+// directions, so 3 generator columns per block (unit forcing e_d) stand for its 8 joint columns: one lane per
+// (generator | throttle column | affine column) and half runs the forward recursion with the trajectory held in
+// REGISTERS (9 N doubles), then the adjoint recursion backwards, and leaves in LDS
+//     sH [half][pair(bc <= br)][a][d]  = sum_{i in br} W_gen(bc, d)(i)[a]          (KIND 0, generator lanes)
+//     sRb[half][c][b][a]               = sum_{i in b} W_c(i)[a]                     (KIND 1, throttle / affine lanes)
+//     sAc[half][c][i - 1][q]           = A_mom[:, q]^T W_c(i),  i >= 1              (tau_0 = 0)
+// from which p1s_entries forms every entry of C directly in the accumulator layout of the owning wavefront:
+//     joint x joint        Lambda[:, qr]^T sH Lambda[:, qc]                               (summed over the halves)
+//     throttle x joint     Lambda[:, qc]^T sRb[cr][bc]
+//     throttle x throttle  sum_i tau^cc_i sAc[cr][i][q_cc]      (row = affine column: the condensed gradient)
+// O(N^2) small 3x3 work (~0.3 MFLOP at the paper horizon) instead of the SYRK over the 18 N weighted sensitivity rows
+// (3.8 MFLOP executed).  The affine column carries x0, c and the reference: W_aff(i) = gamma_i.
+// ------------------------------------------------------------------------------------------------
+// a wave-uniform double moved into scalar registers (v_fma_f64 takes one scalar operand pair): the coefficient matrices of
+// a chain cost no vector registers, which is what lets the 9 N doubles of the trajectory stay in them
+VS_DEV double uniform_f64(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+template <class D, int KIND>
+VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict__ sm) {
+    using S = Smem<D>;
+    constexpr int N = D::N, HC = D::HC, NV = D::NV;
+    const double* sA = sm + S::oA;
+    const double* sCfg = sm + S::oCfg;
+    double* sH = sm + S::oSH;
+    double* sRb = sm + S::oSRb;
+    double* sW3 = sm + S::oSW3;
+    const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;   // state rows of this half
+    const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;   // weighted-row slots (CFG_SQ, reference rows)
+    // wave-uniform coefficients, in scalar registers.  A[h, h] = -S(omega) (systemDynamicsVSMPC.cpp:90-91,301-302) is
+    // skew-symmetric with a zero diagonal: three numbers, and its transpose is its negative
+    double M1[9], qx[3], qh[3], qe[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) M1[3 * r + c] = uniform_f64(sA[(xr0 + r) * NX + hr0 + c]);
+        const double sx = sCfg[CFG_SQ + yx0 + r], sh = sCfg[CFG_SQ + yh0 + r], se = sCfg[CFG_SQ + ye0 + r];
+        qx[r] = uniform_f64(sx * sx);
+        qh[r] = uniform_f64(sh * sh);
+        qe[r] = uniform_f64(se * se);
+    }
+    const double s01 = uniform_f64(sA[(hr0 + 0) * NX + hr0 + 1]), s02 = uniform_f64(sA[(hr0 + 0) * NX + hr0 + 2]),
+                 s12 = uniform_f64(sA[(hr0 + 1) * NX + hr0 + 2]);
+    // lane -> column
+    constexpr int NLIVE = KIND == 0 ? 3 * HC : NV + 1;
+    const bool live = lane < NLIVE;
+    const int col = live ? lane : NLIVE - 1;        // idle lanes shadow the last column and store nothing
+    const int gb = col / 3, gd = col - 3 * gb;      // KIND 0: joint block, momentum direction
+    const bool affl = KIND == 1 && col == NV;       // KIND 1: the affine column
+    // x carries x + c_e throughout (e' = x + c_e; the offset is folded into the reference the affine column reads)
+    double dir[3];
+    double x[3], h[3], e[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if constexpr (KIND == 0) {
+            dir[r] = gd == r ? 1.0 : 0.0;
+            x[r] = 0.0; h[r] = 0.0; e[r] = 0.0;
+        } else {
+            const double a_q = sA[(hr0 + r) * NX + 12 + (col & 3)];
+            dir[r] = affl ? 0.0 : a_q;
+            const double x0 = sm[S::oIn + VSMPC_IN_X0 + xr0 + r], h0 = sm[S::oIn + VSMPC_IN_X0 + hr0 + r],
+                         e0 = sm[S::oIn + VSMPC_IN_X0 + er0 + r];
+            const double ce0 = sm[S::oC + er0 + r];
+            x[r] = affl ? x0 + ce0 : 0.0;
+            h[r] = affl ? h0 : 0.0;
+            e[r] = affl ? e0 : 0.0;
+        }
+    }
+    // per-lane operand rows (KIND 1), as offsets into the workgroup's LDS: the jet's thrust trajectory; the affine column
+    // reads its forcing A_mom Tbar_k + c_h and the reference where every other column reads zeros (no select in the chain)
+    const int tauOff = (KIND == 1 && !affl) ? S::oJetT + col * N : S::oSZero;
+    const int gaOff = affl ? S::oGA + half * 3 * N : S::oSZero;
+    const int refOff = affl ? S::oSRefC : S::oSZero;
+    const double* tauRow = sm + tauOff;
+    const double* gaRow = sm + gaOff;
+    const double* refRow = sm + refOff;
+    // ---- forward: xi_{k+1} = xi_k + dt_k (K xi_k + forcing).  Only the momentum part of the trajectory is kept (3 N
+    // doubles; the whole trajectory would be 18 N registers): x and e are rolled BACK in the adjoint pass, which explicit
+    // Euler allows exactly up to rounding (x_m = x_{m+1} - dt_m M1 h_m, e_m = e_{m+1} - dt_m (x_m + c_e)).
+    // Operands of stage k + 1 are requested at the top of stage k behind an offset the compiler cannot see through:
+    // otherwise the loads of ALL stages are hoisted to the top of the unrolled chain and the trajectory gets spilled.
+    double hk[N][3];
+    double tk_n = 0.0, ga_n[3] = {0.0, 0.0, 0.0};
+    if constexpr (KIND == 1) {
+        tk_n = tauRow[0];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ga_n[r] = gaRow[r];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double dt = cfg.dt[k];   // kernel argument: a scalar load
+        double f[3];
+        if constexpr (KIND == 0) {
+            const double act = joint_block_of_stage<D>(k) == gb ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) f[r] = act * dir[r];
+        } else {
+            const double tk = tk_n;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) f[r] = fma(tk, dir[r], ga_n[r]);
+            if (k + 1 < N) {
+                int zo = 0;
+                asm volatile("" : "+v"(zo));
+                tk_n = tauRow[k + 1 + zo];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ga_n[r] = gaRow[3 * (k + 1) + r + zo];
+            }
+        }
+        double dx[3], dh[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dx[r] = fma(M1[3 * r + 2], h[2], fma(M1[3 * r + 1], h[1], M1[3 * r] * h[0]));
+        }
+        dh[0] = fma(s02, h[2], fma(s01, h[1], f[0]));
+        dh[1] = fma(s12, h[2], fma(-s01, h[0], f[1]));
+        dh[2] = fma(-s12, h[1], fma(-s02, h[0], f[2]));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            e[r] = fma(dt, x[r], e[r]);           // explicit Euler: the old x (+ c_e)
+            x[r] = fma(dt, dx[r], x[r]);
+            h[r] = fma(dt, dh[r], h[r]);
+        }
+        // The state passes through an (empty) volatile statement at every stage boundary: volatile statements keep their
+        // order, so stage k + 1 cannot start before stage k is complete.  Without it the instruction selector emits the
+        // h chain of all stages first and the x and e chains afterwards, with every intermediate x_k alive in between.
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) hk[k][r] = h[r];   // h of node k + 1
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- backward: nu(m) = Q w_m + Abar_m^T nu(m + 1), m = N .. 1, w_m = xi_m (minus the reference on the affine column);
+    // W(i) = dt_i nu(i + 1)[h].  (x, e) hold node m at the top of step m.
+    double nx[3] = {0.0, 0.0, 0.0}, nh[3] = {0.0, 0.0, 0.0}, ne[3] = {0.0, 0.0, 0.0}, bs[3] = {0.0, 0.0, 0.0};
+    double rf_n[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (KIND == 1) {
+        constexpr int rcN = N - 1 < D::NS ? 0 : N - 1 - D::NS;   // reference column of node N (costsVSMPC.cpp:191-200)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { rf_n[r] = refRow[rcN * 12 + yx0 + r]; rf_n[3 + r] = refRow[rcN * 12 + yh0 + r]; }
+    }
+#pragma unroll
+    for (int m = N; m >= 1; --m) {
+        const int i = m - 1;
+        double rf[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) rf[r] = rf_n[r];
+        if constexpr (KIND == 1) {
+            if (m >= 2) {
+                int zo = 0;
+                asm volatile("" : "+v"(zo));
+                const int rc = m - 2 < D::NS ? 0 : m - 2 - D::NS;   // reference column of node m - 1
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    rf_n[r] = refRow[rc * 12 + yx0 + r + zo];
+                    rf_n[3 + r] = refRow[rc * 12 + yh0 + r + zo];
+                }
+            }
+        }
+        if (m < N) {
+            const double dtm = cfg.dt[m];
+            double t[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) t[r] = fma(M1[6 + r], nx[2], fma(M1[3 + r], nx[1], M1[r] * nx[0]));
+            t[0] = fma(-s02, nh[2], fma(-s01, nh[1], t[0]));   // + Sk^T nu_h = - Sk nu_h
+            t[1] = fma(-s12, nh[2], fma(s01, nh[0], t[1]));
+            t[2] = fma(s12, nh[1], fma(s02, nh[0], t[2]));
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                nx[r] = fma(dtm, ne[r], nx[r]);   // K^T: the x rows of the adjoint collect the e rows (A[e, x] = I)
+                nh[r] = fma(dtm, t[r], nh[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            nx[r] = fma(qx[r], KIND == 1 ? x[r] - rf[r] : x[r], nx[r]);
+            nh[r] = fma(qh[r], KIND == 1 ? hk[i][r] - rf[3 + r] : hk[i][r], nh[r]);
+            ne[r] = fma(qe[r], e[r], ne[r]);
+        }
+        const double dti = cfg.dt[i];
+        if (m >= 2) {   // roll (x, e) back to node m - 1 with h of node m - 1
+            // (opaque copies: otherwise the compiler recognises M1 h of the forward pass and keeps all N of them alive
+            // -- in scratch -- instead of recomputing, which is the whole point of keeping only h)
+            double hp[3] = {hk[i - 1][0], hk[i - 1][1], hk[i - 1][2]};
+            asm volatile("" : "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]));
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double dxr = fma(M1[3 * r + 2], hp[2], fma(M1[3 * r + 1], hp[1], M1[3 * r] * hp[0]));
+                x[r] = fma(-dti, dxr, x[r]);
+                e[r] = fma(-dti, x[r], e[r]);
+            }
+        }
+        double w[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { w[a] = dti * nh[a]; bs[a] += w[a]; }
+        if constexpr (KIND == 1) {
+            if (i >= 1 && live) {
+                double* Wp = sW3 + ((half * (NV + 1) + col) * (N - 1) + (i - 1)) * 3;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) Wp[a] = w[a];
+            }
+        }
+        if (i < HC) {   // i is the first stage of joint block jb(i) = i (the last block spans stages HC-1 .. N-1)
+            if constexpr (KIND == 0) {
+                if (live && i >= gb) {
+                    double* Hp = sH + (half * D::NJPAIR + i * (i + 1) / 2 + gb) * 9 + gd;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) Hp[3 * a] = bs[a];
+                }
+            } else {
+                if (live) {
+                    double* Rp = sRb + ((half * (NV + 1) + col) * HC + i) * 3;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) Rp[a] = bs[a];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) bs[a] = 0.0;
+        }
+        asm volatile("" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nh[0]), "+v"(nh[1]), "+v"(nh[2]), "+v"(ne[0]), "+v"(ne[1]), "+v"(ne[2]));
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(bs[0]), "+v"(bs[1]), "+v"(bs[2]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// sAc[c][i - 1][q] = sum over the halves of A_mom,half[:, q]^T W_c(i): the throttle x throttle tiles read it as a matrix-core
+// operand.  All wavefronts, between the chains and the entries.
+template <class D>
+VS_DEV void p1s_contract(double* __restrict__ sm, int tid) {
+    using S = Smem<D>;
+    constexpr int NI = (D::NV + 1) * (D::N - 1);
+    const double* sA = sm + S::oA;
+    const double* sW3 = sm + S::oSW3;
+    double* sAc = sm + S::oSAc;
+    for (int item = tid; item < NI * 4; item += D::BLOCK) {
+        const int ci = item >> 2, q = item & 3;
+        const double* w0 = sW3 + ci * 3;
+        const double* w1 = sW3 + (NI + ci) * 3;
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v = fma(sA[(3 + a) * NX + 12 + q], w0[a], v);
+            v = fma(sA[(9 + a) * NX + 12 + q], w1[a], v);
+        }
+        sAc[item] = v;
+    }
+}
+
+// Entries of C = sum_k Y_k^T Y_k for the accumulator tiles wavefront W owns, formed ON THE MATRIX CORES from the small LDS
+// arrays the chains leave behind, so that they arrive in the accumulator layout (lane (g, j) holds rows g + 4 r, column j)
+// with a handful of LDS reads per tile.  With L = [Lambda_lin; Lambda_ang] (6 x 8) and k = (block-in-tile kb, a6):
+//   joint x joint        D = A B,  A[m][k] = [kb == m >> 3] L[a6][m & 7]  (the same for every tile),
+//                        B[k][n] = (H^(2 ti + kb, 2 tj + (n >> 3)) L)[a6][n & 7]                      3 k-steps
+//   throttle x joint     A[m][k] = sRb[half(a6)][row m][2 tj + kb][a],  B = the constant operand       3 k-steps
+//   throttle x throttle  k = (i', q): A[m][k] = sAc[row m][i'][q],  B[k][n] = [q == q_n] tau^n_{i' + 1}    N - 1 k-steps
+template <class D, int TPW, int W>
+VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane) {
+    using S = Smem<D>;
+    constexpr int PVT = D::PVT, N = D::N, HC = D::HC, NV = D::NV;
+    static_assert(D::NU % 16 == 0, "joint rows are tile aligned");
+    const double* sBj = sm + S::oBj;
+    const double* sH = sm + S::oSH;
+    const double* sRb = sm + S::oSRb;
+    const double* sAc = sm + S::oSAc;
+    const double* sJetT = sm + S::oJetT;
+    const int j = lane & 15, g = lane >> 4;
+    const int jq = j & 7, jb1 = j >> 3;
+    int kb[3], hf[3], aa[3];
+    double Lc[3], Lq[3][3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int k = 4 * ks + g;
+        kb[ks] = k >= 6 ? 1 : 0;
+        const int a6 = k - 6 * kb[ks];
+        hf[ks] = a6 >= 3 ? 1 : 0;
+        aa[ks] = a6 - 3 * hf[ks];
+        const int hr0 = hf[ks] ? 9 : 3;
+        const double lv = sBj[(hr0 + aa[ks]) * NJ + jq];
+        Lc[ks] = kb[ks] == jb1 ? lv : 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) Lq[ks][d] = sBj[(hr0 + d) * NJ + jq];
+    }
+    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+        constexpr TileTab<D> tab{};
+        constexpr int q = decltype(qcst)::value;
+        constexpr int t = q * D::NWAVES + W;
+        d4 c = d4{0.0, 0.0, 0.0, 0.0};
+        if constexpr (t < D::NTRI) {
+            constexpr int ti = tab.ti[t], tj = tab.tj[t];
+            if constexpr (ti < PVT) {
+                const int bc = 2 * tj + jb1;
+                double bop[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int br = 2 * ti + kb[ks];
+                    bool sw = false;                 // upper half of a diagonal tile: the transposed block
+                    int hi = br, lo = bc;
+                    if constexpr (ti == tj) { sw = br < bc; hi = sw ? bc : br; lo = sw ? br : bc; }
+                    const double* Hp = sH + (hf[ks] * D::NJPAIR + hi * (hi + 1) / 2 + lo) * 9 + (sw ? aa[ks] : 3 * aa[ks]);
+                    const int st = sw ? 3 : 1;
+                    bop[ks] = fma(Hp[2 * st], Lq[ks][2], fma(Hp[st], Lq[ks][1], Hp[0] * Lq[ks][0]));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[ks], bop[ks], c, 0, 0, 0);
+            } else if constexpr (tj < PVT) {
+                const int cr = 16 * (ti - PVT) + j;
+                const bool ok = cr <= NV;
+                const int crc = ok ? cr : NV;
+                double aop[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const double v = sRb[((hf[ks] * (NV + 1) + crc) * HC + 2 * tj + kb[ks]) * 3 + aa[ks]];
+                    aop[ks] = ok ? v : 0.0;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ks], Lc[ks], c, 0, 0, 0);
+            } else {
+                const int cr = 16 * (ti - PVT) + j, cc = 16 * (tj - PVT) + j;
+                const bool okr = cr <= NV, okc = cc < NV && g == (cc & 3);
+                const double* Ap = sAc + (okr ? cr : NV) * (N - 1) * 4 + g;
+                const double* Tp = sJetT + (cc < NV ? cc : 0) * N + 1;
+#pragma unroll
+                for (int ks = 0; ks < N - 1; ++ks) {
+                    const double av = Ap[4 * ks], bv = Tp[ks];
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(okr ? av : 0.0, okc ? bv : 0.0, c, 0, 0, 0);
+                }
+            }
+        }
+        acc[q] = c;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
 // the solve kernel
 // ------------------------------------------------------------------------------------------------
 // Kernel-argument block as it lies in the kernarg segment.  Everything but `in` and `batch` is needed late (outputs) or
@@ -1333,13 +1700,11 @@ VS_DEV const SolveArgs* late_args() {
 
 // STAMPS = true is the diagnostic build: thread 0 records s_memtime at every phase boundary into
 // `stamps` (its own buffer, never read by the kernel).  The shipped instantiation has STAMPS = false.
-// LAT (latency form, batches that leave CUs to spare): eight wavefronts, one workgroup per CU.  Wavefronts 4..7 run the
-// sensitivity recursion of pass m + 1 into a second Y buffer while wavefronts 0..3 run the SYRK of pass m (one barrier
-// per pass), and end after the last pass; a barrier only counts the wavefronts that are still alive, so P2..P6 are the
-// four-wavefront code unchanged.  The throughput form (two workgroups per CU) hides the recursion behind the
-// co-resident workgroup instead and needs the LDS for it.
-template <class D, bool STAMPS, int LAT = 0>
-__global__ __launch_bounds__(LAT == 1 ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
+// FORM selects how P1 condenses: 0 = sensitivity recursion + SYRK on the matrix cores (every horizon), 1 = structured
+// condensing (P1s, horizons with Dims::STRUCT_P1; the default there).  Everything from P2 on is the same code; the two
+// forms agree to rounding (different summation order), which tests/test_gpu_parity.py checks on the device.
+template <class D, bool STAMPS, int FORM = 0>
+__global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* xout_, double* fmout_, int* status_out_,
                                                          int* iters_out_, double* dbgM_, double* dbgL_,
                                                          unsigned long long* stamps_) {
@@ -1430,8 +1795,7 @@ __global__ __launch_bounds__(LAT == 1 ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG
             sCfg[CFG_WREG] = cfg.w_reg; sCfg[CFG_WTHR] = cfg.w_thr; sCfg[CFG_WINIT] = cfg.w_init;
             sCfg[CFG_VMIN] = cfg.vmin; sCfg[CFG_VMAX] = cfg.vmax;
         }
-        if (tid < D::BLOCK)   // (the recursion wavefronts of the latency form take no part in P0)
-            for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
+        for (int i = tid; i < NX * NX + NX * NJ + NX * NTH + 28; i += D::BLOCK) sA[i] = 0.0;  // A,Bj,Bt,c contiguous
         if (tid < D::NIN / 2) sIn2[tid] = rec;
     }
     __syncthreads();
@@ -1473,12 +1837,20 @@ __global__ __launch_bounds__(LAT == 1 ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG
         for (int k = lane; k < D::N; k += 64) sJetT[ZROW * D::N + k] = 0.0;
     }
     __syncthreads();   // ends P0 and the jet trajectories
-    for (int e = tid; e < 6 * D::N && tid < D::BLOCK; e += D::BLOCK) {
+    if constexpr (FORM == 1) {
+        for (int e = tid; e < S::sizeZero; e += D::BLOCK) smem[S::oSZero + e] = 0.0;
+        for (int e = tid; e < 12 * D::NREF; e += D::BLOCK) {   // reference window + c_e on the CoM / RPY rows
+            const int row = e % 12;
+            const double off = row < 3 ? sC[20 + row] : ((row >= 6 && row < 9) ? sC[23 + row - 6] : 0.0);
+            smem[S::oSRefC + e] = sIn[VSMPC_IN_XREF + e] + off;
+        }
+    }
+    for (int e = tid; e < 6 * D::N; e += D::BLOCK) {
         const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3, row = (h ? 9 : 3) + r;
         double g = 0.0;
 #pragma unroll
         for (int c = 0; c < NTH; ++c) g = fma(sA[row * NX + 12 + c], sJetT[(D::NV + c) * D::N + k], g);
-        sGA[e] = g;
+        sGA[e] = FORM == 1 ? g + sC[row] : g;   // P1s: the affine column's whole momentum forcing A_mom Tbar_k + c_h
     }
     __syncthreads();
 
@@ -1487,18 +1859,36 @@ __global__ __launch_bounds__(LAT == 1 ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG
     if constexpr (STAMPS) stamp_t1 = __builtin_amdgcn_s_memtime();
     // ---------------------------------------------------------------- P1 condense
     d4 acc[TPW];
+    if constexpr (FORM == 1) {
+        // P1s: structured condensing.  Generator lanes on wavefronts 0 / 1 (linear / angular half), throttle and affine
+        // columns on wavefronts 2 / 3; no communication inside the chains, one barrier, then the entries of the owned
+        // tiles straight into the accumulator registers.
+        static_assert(D::STRUCT_P1, "structured condensing is instantiated for horizons with Dims::STRUCT_P1");
+        VS_TIC();
+        if (wave < 2) p1s_chain<D, 0>(cfg, wave, lane, smem);
+        else p1s_chain<D, 1>(cfg, wave - 2, lane, smem);
+        VS_TOC(0);
+        __syncthreads();
+        VS_TOC(1);
+        p1s_contract<D>(smem, tid);
+        __syncthreads();
+        switch (wave) {
+            case 0: p1s_entries<D, TPW, 0>(acc, smem, lane); break;
+            case 1: p1s_entries<D, TPW, 1>(acc, smem, lane); break;
+            case 2: p1s_entries<D, TPW, 2>(acc, smem, lane); break;
+            default: p1s_entries<D, TPW, 3>(acc, smem, lane); break;
+        }
+        VS_TOC(2);
+        __syncthreads();   // the LDS arrays of P1s lie under the ring P3 is about to fill
+    } else {
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-
-    {
+        for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
         // P1b: thread (half, c): half 0 = linear part (p, h_lin, e_pos), half 1 = angular part (rpy, h_ang, e_rpy) of the
         // condensed columns c, c + 128, ... (CPT of them; one at the paper horizon).  Same code, different coefficient rows.
         constexpr int CPT = D::CPT;
-        // latency form: wavefronts NWAVES.. run the recursion (rec_wave), wavefronts 0..NWAVES-1 the SYRK (mm_wave);
-        // throughput form: every wavefront does both, one after the other
-        const int pw = LAT == 1 ? (wave & (D::NWAVES - 1)) : wave;
-        const int ptid = LAT == 1 ? (tid & (D::BLOCK - 1)) : tid;
-        const bool rec_wave = LAT != 1 || wave >= D::NWAVES, mm_wave = LAT != 1 || wave < D::NWAVES;
+        // every wavefront runs the recursion of a pass, then its share of the SYRK
+        const int pw = wave;
+        const int ptid = tid;
         const int half = pw / (D::NWAVES / 2);  // scalar
         const int xr0 = half ? 6 : 0, hr0 = half ? 9 : 3, er0 = half ? 23 : 20;  // state rows
         const int yx0 = half ? 6 : 0, yh0 = half ? 9 : 3, ye0 = half ? 15 : 12;  // weighted-row slots
@@ -1648,61 +2038,14 @@ __global__ __launch_bounds__(LAT == 1 ? 2 * D::BLOCK : D::BLOCK, LAT ? 1 : D::WG
 #pragma unroll
                 for (int q = NACT - 1; q >= 0; --q) {
                     const int qn = q > 0 ? q - 1 : 0;
-                    syrk_slot<D, NKS, VS_SYRK_TIED, LAT != 2>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
+                    syrk_slot<D, NKS, VS_SYRK_TIED, true>(acc[q], slot_a(q), slot_b(q), ha, hb, slot_a(qn), slot_b(qn));
 #ifdef VS_DIAG_SPLIT   // measurement builds: time of the first chain of every pass -> sub-phase 3
                     if (q == NACT - 1) VS_TOC(3);
 #endif
                 }
             }
         };
-        if constexpr (LAT == 2) {
-            // four wavefronts, two Y buffers: the recursion of pass m + 1 and the SYRK of pass m in ONE instruction stream
-            // (no scheduling pins: the compiler fills the 64-cycle shadow of every matrix instruction with the
-            // recursion's loads, address arithmetic and stores; FP64 vector instructions share the unit with the matrix
-            // instructions and add their own issue time)
-            rec_pass(0, (1 < D::N) ? 2 : 1, sY);
-            __syncthreads();
-            static_for<0, NPASS>([&](auto mc) __attribute__((always_inline)) {
-                constexpr int m = decltype(mc)::value;
-                VS_TIC();
-                ybase = sY + (m & 1) * S::sizeY + ylane;
-                if constexpr (m + 1 < NPASS) rec_pass(m + 1, (2 * m + 3 < D::N) ? 2 : 1, sY + ((m + 1) & 1) * S::sizeY);
-                syrk_fixed(std::integral_constant<int, (2 * m + 1 < D::N) ? 9 : 5>{},
-                           std::integral_constant<int, nact_max<D>(m)>{});
-                VS_TOC(2);
-                __syncthreads();
-            });
-        } else if constexpr (LAT == 1) {
-            static_assert(UNROLLED, "the latency forms exist for the short horizons");
-            // two loops that meet at one barrier per pass: pass m + 1 of the recursion runs beside pass m of the SYRK
-            if (rec_wave) {
-#ifdef VS_PRODUCER_PRIO
-                __builtin_amdgcn_s_setprio(VS_PRODUCER_PRIO);
-#endif
-#pragma unroll 1
-                for (int m = 0; m < NPASS; ++m) {
-                    rec_pass(m, (2 * m + 1 < D::N) ? 2 : 1, sY + (m & 1) * S::sizeY);
-                    __syncthreads();
-                }
-                return;   // later barriers count the live wavefronts only
-            }
-            if constexpr (UNROLLED) {
-                static_for<0, NPASS>([&](auto mc) __attribute__((always_inline)) {
-                    constexpr int m = decltype(mc)::value;
-                    VS_TIC();
-                    ybase = sY + (m & 1) * S::sizeY + ylane;
-                    VS_TOC(0);
-                    __syncthreads();
-                    VS_TOC(1);
-                    syrk_fixed(std::integral_constant<int, (2 * m + 1 < D::N) ? 9 : 5>{},
-                               std::integral_constant<int, nact_max<D>(m)>{});
-#ifdef VS_DIAG_PASS   // measurement builds: the matrix-core time of ONE pass (tools/exp_build.sh)
-                    if (m != VS_DIAG_PASS) { VS_TIC(); } else
-#endif
-                    VS_TOC(2);
-                });
-            }
-        } else if constexpr (UNROLLED) {
+        if constexpr (UNROLLED) {
             static_for<0, NPASS>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value;
                 constexpr int nnodes = (2 * m + 1 < D::N) ? 2 : 1;
@@ -2217,68 +2560,44 @@ hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipS
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_DEVICES = 64;
 
-// compute units of a device (cached): a batch that leaves none of them with two instances runs the latency form
-static hipError_t device_cus(int dev, int* cus) {
-    static int cached[MAX_DEVICES] = {};
-    if (cached[dev] == 0) {
-        int n = 0;
-        hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-        cached[dev] = n > 0 ? n : 1;
-    }
-    *cus = cached[dev];
-    return hipSuccess;
+// condensing form of a handle: 0 = the default of the horizon (structured where Dims::STRUCT_P1), 1 = structured,
+// 2 = SYRK (vsmpc_set_kernel_form).  VSMPC_FORM=structured|syrk is what a new handle starts with, for measurements of
+// unmodified programs.
+int initial_kernel_form() {
+    const char* v = getenv("VSMPC_FORM");
+    return (v != nullptr && v[0] == 's' && v[1] == 't') ? 1 : (v != nullptr && v[0] == 's' && v[1] == 'y') ? 2 : 0;
 }
 
-// kernel form: 0 by batch size, 1 throughput, 2 latency (vsmpc_set_kernel_form; VSMPC_FORM=throughput|latency sets
-// the initial value for measurements of unmodified programs)
-static int g_form = -1;
-static int forced_form() {
-    if (g_form < 0) {
-        const char* v = getenv("VSMPC_FORM");
-        g_form = (v != nullptr && v[0] == 't') ? 1 : (v != nullptr && v[0] == 'l') ? 2 : 0;
-    }
-    return g_form;
-}
-int set_kernel_form(int form) {
-    const int prev = forced_form();
-    g_form = form;
-    return prev;
-}
-
-template <class D, bool STAMPS, int LAT>
+template <class D, bool STAMPS, int FORM>
 static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
                                  unsigned long long* stamps, hipStream_t stream) {
     // the dynamic-LDS limit is a per-device function attribute: one process may drive several devices
     static bool attr_set[MAX_DEVICES] = {};
-    constexpr size_t lds = LAT ? Smem<D>::bytes_lat : Smem<D>::bytes;
+    constexpr size_t lds = FORM == 1 ? Smem<D>::bytes_struct : Smem<D>::bytes;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS, LAT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS, FORM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((solve_kernel<D, STAMPS, LAT>), dim3(batch), dim3(LAT == 1 ? 2 * D::BLOCK : D::BLOCK), lds, stream,
+    hipLaunchKernelGGL((solve_kernel<D, STAMPS, FORM>), dim3(batch), dim3(D::BLOCK), lds, stream,
                        cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
     return hipGetLastError();
 }
 
 template <class D, bool STAMPS>
-static hipError_t launch_solve_t(const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+static hipError_t launch_solve_t(int form, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
                                  unsigned long long* stamps, hipStream_t stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
-    if constexpr (D::WG_PER_CU >= 2) {   // horizons whose wavefronts fit 256 registers: two forms
-        int cus = 0;
-        if ((e = device_cus(dev, &cus)) != hipSuccess) return e;
-        const int form = forced_form();
-        if (form == 2 || (form == 0 && batch <= cus))
-            return launch_solve_f<D, STAMPS, VS_LAT_FORM>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
-                                                   stamps, stream);
+    if constexpr (D::STRUCT_P1) {
+        if (form != 2)
+            return launch_solve_f<D, STAMPS, 1>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
+                                                stream);
     }
     return launch_solve_f<D, STAMPS, 0>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
                                             stream);
@@ -2295,11 +2614,12 @@ struct HorizonEntry {
     int n_iter, n_iter_small, control_horizon, n_p;
     size_t lds_bytes;
     const char* name;
+    bool structured;
 };
 #define VSMPC_STR2(x) #x
 #define VSMPC_STR(x) VSMPC_STR2(x)
 static const HorizonEntry kHorizons[] = {
-#define X(N, NS, HC) {N, NS, HC, Dims<N, NS, HC>::NP, Smem<Dims<N, NS, HC>>::bytes, "solve_kernel<Dims<" VSMPC_STR(N) "," VSMPC_STR(NS) "," VSMPC_STR(HC) ">>"},
+#define X(N, NS, HC) {N, NS, HC, Dims<N, NS, HC>::NP, Dims<N, NS, HC>::STRUCT_P1 ? Smem<Dims<N, NS, HC>>::bytes_struct : Smem<Dims<N, NS, HC>>::bytes, "solve_kernel<Dims<" VSMPC_STR(N) "," VSMPC_STR(NS) "," VSMPC_STR(HC) ">>", Dims<N, NS, HC>::STRUCT_P1},
 #include "vsmpc_horizons.def"
 #undef X
 };
@@ -2330,20 +2650,24 @@ int variant_condensed_dim(int variant) {
     return (variant >= 1 && variant <= kNumHorizons) ? kHorizons[variant - 1].n_p : 0;
 }
 
+bool variant_has_structured(int variant) {
+    return variant >= 1 && variant <= kNumHorizons && kHorizons[variant - 1].structured;
+}
+
 size_t variant_lds_bytes(int variant) {
     return (variant >= 1 && variant <= kNumHorizons) ? kHorizons[variant - 1].lds_bytes : 0;
 }
 
-hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+hipError_t launch_solve(int variant, int form, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                         int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
                         hipStream_t stream) {
     int id = 0;
 #define X(N, NS, HC)                                                                                                  \
     if (variant == ++id) {                                                                                            \
         if (stamps != nullptr)                                                                                        \
-            return launch_solve_t<Dims<N, NS, HC>, true>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,  \
+            return launch_solve_t<Dims<N, NS, HC>, true>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,  \
                                                          stamps, stream);                                             \
-        return launch_solve_t<Dims<N, NS, HC>, false>(cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,     \
+        return launch_solve_t<Dims<N, NS, HC>, false>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,     \
                                                       nullptr, stream);                                               \
     }
 #include "vsmpc_horizons.def"

@@ -18,9 +18,11 @@ const char* variant_kernel_name(int variant);
 int variant_condensed_dim(int variant);
 size_t variant_lds_bytes(int variant);  // dynamic LDS of one workgroup (<= 80 KB: two workgroups share a CU)
 
-int set_kernel_form(int form);  // 0 by batch size, 1 throughput, 2 latency; returns the previous value
+int initial_kernel_form();               // VSMPC_FORM: what a new handle starts with
+bool variant_has_structured(int variant);
 
-hipError_t launch_solve(int variant, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+// form: 0 the horizon's default (structured condensing where available), 1 structured, 2 SYRK
+hipError_t launch_solve(int variant, int form, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                         int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
                         hipStream_t stream);
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,

@@ -24,16 +24,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-KERNEL_FORM_AUTO, KERNEL_FORM_THROUGHPUT, KERNEL_FORM_LATENCY = 0, 1, 2
-
-
-def set_kernel_form(form: int) -> int:
-    """vsmpc_set_kernel_form (include/vsmpc.h): pins the throughput / latency form of the solve kernel process-wide;
-    returns the previous setting."""
-    prev = _lib.load().vsmpc_set_kernel_form(int(form))
-    if prev < 0:
-        raise ValueError(f"kernel form {form}")
-    return prev
+KERNEL_FORM_AUTO, KERNEL_FORM_STRUCTURED, KERNEL_FORM_SYRK = 0, 1, 2
 
 
 class BatchedVSMPC:
@@ -53,6 +44,14 @@ class BatchedVSMPC:
         self.n_in = self.lib.vsmpc_input_doubles(self._h)
         self.n_p = self.lib.vsmpc_condensed_dim(self._h)
         assert self.n_var == self.cfg.n_var and self.n_in == self.cfg.n_in and self.n_con == self.cfg.n_con
+
+    def set_kernel_form(self, form: int) -> int:
+        """vsmpc_set_kernel_form (include/vsmpc.h): how this handle's solve kernel condenses the QP (structured
+        forward / adjoint recursions, or sensitivity recursion + SYRK); returns the previous setting."""
+        prev = self.lib.vsmpc_set_kernel_form(self._h, int(form))
+        if prev < 0:
+            raise ValueError(f"kernel form {form}: {self.lib.vsmpc_strerror(prev).decode()}")
+        return prev
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

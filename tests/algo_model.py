@@ -34,12 +34,11 @@ def column_maps(cfg):
     return cols
 
 
-def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None):
-    """`oracle` is the oracle module (for linearize/dt_schedule helpers that restate the reference);
-    everything downstream of (A, Bj, Bt, c) is the kernel's own algorithm."""
+def condense_syrk(cfg, oracle, inp):
+    """P1 as the sensitivity recursion + SYRK (kernels up to v12): the padded C = sum_k Y_k^T Y_k, whose row / column
+    NZ (the affine column) holds the condensed gradient of the tracking cost."""
     N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
-    nvb = cfg.n_vblocks
-    NU, NV = 8 * H, 4 * nvb
+    NU, NV = 8 * H, 4 * cfg.n_vblocks
     NZ = NU + NV
     NP = ((NZ + 1 + 15) // 16) * 16
     A, Bj, Bt, c = oracle.linearize(cfg, inp)
@@ -47,12 +46,7 @@ def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None):
     qd = oracle.state_weight(cfg)
     sq = np.sqrt(qd[W_ROWS])
     cols = column_maps(cfg)
-    vmin, vmax = oracle.throttle_bounds(cfg)
-    vprev = np.array([oracle.v_of_throttle(inp[oracle.IN_UPREV + i]) for i in range(4)])
-    hold = inp[oracle.IN_HOLD] != 0.0
     xref_win = inp[oracle.IN_XREF:oracle.IN_XREF + 12 * cfg.n_ref_cols].reshape(cfg.n_ref_cols, 12)
-
-    # ---- P1 condense
     S = np.zeros((26, NP))
     S[:, NZ] = inp[0:26]  # affine column starts at x0
     C = np.zeros((NP, NP))
@@ -75,6 +69,30 @@ def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None):
         Sa[:, NZ] -= xr
         Y = sq[:, None] * Sa[W_ROWS, :]
         C += Y.T @ Y
+
+    return C
+
+
+def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None, condense=None):
+    """`oracle` is the oracle module (for linearize/dt_schedule helpers that restate the reference);
+    everything downstream of (A, Bj, Bt, c) is the kernel's own algorithm."""
+    N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
+    nvb = cfg.n_vblocks
+    NU, NV = 8 * H, 4 * nvb
+    NZ = NU + NV
+    NP = ((NZ + 1 + 15) // 16) * 16
+    A, Bj, Bt, c = oracle.linearize(cfg, inp)
+    dts = oracle.dt_schedule(cfg)
+    qd = oracle.state_weight(cfg)
+    sq = np.sqrt(qd[W_ROWS])
+    cols = column_maps(cfg)
+    vmin, vmax = oracle.throttle_bounds(cfg)
+    vprev = np.array([oracle.v_of_throttle(inp[oracle.IN_UPREV + i]) for i in range(4)])
+    hold = inp[oracle.IN_HOLD] != 0.0
+    xref_win = inp[oracle.IN_XREF:oracle.IN_XREF + 12 * cfg.n_ref_cols].reshape(cfg.n_ref_cols, 12)
+
+    # ---- P1 condense
+    C = condense_syrk(cfg, oracle, inp) if condense is None else condense(cfg, oracle, inp)
 
     # ---- P2 augment with R and the input-cost gradient
     M = C.copy()
