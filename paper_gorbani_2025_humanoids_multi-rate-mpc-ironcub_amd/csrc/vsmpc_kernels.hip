@@ -1565,35 +1565,55 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
 }
 
 // sAc[c][i - 1][q] = sum over the halves of A_mom,half[:, q]^T W_c(i): the throttle x throttle tiles read it as a matrix-core
-// operand.  All wavefronts, between the chains and the entries.
+// operand.  All wavefronts, between the chains and the entries: one (c, i) pair and its four q per thread and round.
 template <class D>
 VS_DEV void p1s_contract(double* __restrict__ sm, int tid) {
     using S = Smem<D>;
     constexpr int NI = (D::NV + 1) * (D::N - 1);
+    constexpr int ROUNDS = (NI + D::BLOCK - 1) / D::BLOCK;
     const double* sA = sm + S::oA;
     const double* sW3 = sm + S::oSW3;
     double* sAc = sm + S::oSAc;
-    for (int item = tid; item < NI * 4; item += D::BLOCK) {
-        const int ci = item >> 2, q = item & 3;
-        const double* w0 = sW3 + ci * 3;
-        const double* w1 = sW3 + (NI + ci) * 3;
-        double v = 0.0;
+    double w[ROUNDS][6];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            v = fma(sA[(3 + a) * NX + 12 + q], w0[a], v);
-            v = fma(sA[(9 + a) * NX + 12 + q], w1[a], v);
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int ci = tid + rd * D::BLOCK, cic = ci < NI ? ci : NI - 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { w[rd][a] = sW3[cic * 3 + a]; w[rd][3 + a] = sW3[(NI + cic) * 3 + a]; }
+    }
+    double Am[6][NTH];   // uniform addresses: LDS broadcasts
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < NTH; ++q) { Am[a][q] = sA[(3 + a) * NX + 12 + q]; Am[3 + a][q] = sA[(9 + a) * NX + 12 + q]; }
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int ci = tid + rd * D::BLOCK;
+        double v[NTH];
+#pragma unroll
+        for (int q = 0; q < NTH; ++q) {
+            v[q] = Am[0][q] * w[rd][0];
+#pragma unroll
+            for (int a = 1; a < 6; ++a) v[q] = fma(Am[a][q], w[rd][a], v[q]);
         }
-        sAc[item] = v;
+        if (ci < NI) {
+#pragma unroll
+            for (int q = 0; q < NTH; ++q) sAc[ci * 4 + q] = v[q];
+        }
     }
 }
 
 // Entries of C = sum_k Y_k^T Y_k for the accumulator tiles wavefront W owns, formed ON THE MATRIX CORES from the small LDS
 // arrays the chains leave behind, so that they arrive in the accumulator layout (lane (g, j) holds rows g + 4 r, column j)
-// with a handful of LDS reads per tile.  With L = [Lambda_lin; Lambda_ang] (6 x 8) and k = (block-in-tile kb, a6):
+// with a handful of LDS reads per tile.  With L = [Lambda_lin; Lambda_ang] (6 x 8) and the k index of a product split as
+// k = 4 ks + g  ->  (kb, a6) = (g >> 1, 2 ks + (g & 1))   (kb = block within the tile, a6 = (half, a)):
 //   joint x joint        D = A B,  A[m][k] = [kb == m >> 3] L[a6][m & 7]  (the same for every tile),
 //                        B[k][n] = (H^(2 ti + kb, 2 tj + (n >> 3)) L)[a6][n & 7]                      3 k-steps
 //   throttle x joint     A[m][k] = sRb[half(a6)][row m][2 tj + kb][a],  B = the constant operand       3 k-steps
 //   throttle x throttle  k = (i', q): A[m][k] = sAc[row m][i'][q],  B[k][n] = [q == q_n] tau^n_{i' + 1}    N - 1 k-steps
+// Operands first, matrix instructions afterwards: with the loads of a tile right in front of its instructions every
+// tile pays LDS round trips (~9k cycles for the nine tiles of a wavefront, measured); the accumulators are not live
+// yet, so there are registers for the raw operands of all tiles at once (the loads are pinned in front of the arithmetic).
 template <class D, int TPW, int W>
 VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane) {
     using S = Smem<D>;
@@ -1606,21 +1626,81 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     const double* sJetT = sm + S::oJetT;
     const int j = lane & 15, g = lane >> 4;
     const int jq = j & 7, jb1 = j >> 3;
-    int kb[3], hf[3], aa[3];
+    const int kb = g >> 1;                       // block within the tile this lane's k values belong to
+    int hf[3], aa[3], hoff[3], roff[3];
     double Lc[3], Lq[3][3];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
-        const int k = 4 * ks + g;
-        kb[ks] = k >= 6 ? 1 : 0;
-        const int a6 = k - 6 * kb[ks];
+        const int a6 = 2 * ks + (g & 1);
         hf[ks] = a6 >= 3 ? 1 : 0;
         aa[ks] = a6 - 3 * hf[ks];
         const int hr0 = hf[ks] ? 9 : 3;
         const double lv = sBj[(hr0 + aa[ks]) * NJ + jq];
-        Lc[ks] = kb[ks] == jb1 ? lv : 0.0;
+        Lc[ks] = kb == jb1 ? lv : 0.0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) Lq[ks][d] = sBj[(hr0 + d) * NJ + jq];
+        // everything lane dependent of an operand address, once: what is left per tile is a compile-time offset
+        //   sH : pair(2 ti + kb, 2 tj + jb1) = T(2 ti) + kb (2 ti + 1) + 2 tj + jb1,  T(n) = n (n + 1) / 2
+        hoff[ks] = (hf[ks] * D::NJPAIR + jb1) * 9 + 3 * aa[ks];
+        roff[ks] = hf[ks] * (NV + 1) * HC * 3 + kb * 3 + aa[ks];
     }
+    const int kb9 = 9 * kb;
+    double raw[TPW][3][3];
+    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+        constexpr TileTab<D> tab{};
+        constexpr int q = decltype(qcst)::value;
+        constexpr int t = q * D::NWAVES + W;
+        if constexpr (t < D::NTRI) {
+            constexpr int ti = tab.ti[t], tj = tab.tj[t];
+            if constexpr (ti < PVT && ti != tj) {
+                constexpr int base = ((2 * ti) * (2 * ti + 1) / 2 + 2 * tj) * 9;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const double* Hp = sH + base + hoff[ks] + kb9 * (2 * ti + 1);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) raw[q][ks][d] = Hp[d];
+                }
+            } else if constexpr (ti < PVT) {
+                // diagonal tile: its upper block (row block 2 t, column block 2 t + 1) is the transposed lower one
+                const int br = 2 * ti + kb, bc = 2 * ti + jb1;
+                const bool sw = br < bc;
+                const int hi = sw ? bc : br, lo = sw ? br : bc;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const double* Hp = sH + (hf[ks] * D::NJPAIR + hi * (hi + 1) / 2 + lo) * 9 + (sw ? aa[ks] : 3 * aa[ks]);
+                    const int st = sw ? 3 : 1;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) raw[q][ks][d] = Hp[d * st];
+                }
+            } else if constexpr (tj < PVT) {
+                const int cr = 16 * (ti - PVT) + j;
+                const int crc = cr <= NV ? cr : NV;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) raw[q][ks][0] = sRb[(crc * HC + 2 * tj) * 3 + roff[ks]];
+            }
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    double op[TPW][3];
+    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+        constexpr TileTab<D> tab{};
+        constexpr int q = decltype(qcst)::value;
+        constexpr int t = q * D::NWAVES + W;
+        op[q][0] = op[q][1] = op[q][2] = 0.0;
+        if constexpr (t < D::NTRI) {
+            constexpr int ti = tab.ti[t], tj = tab.tj[t];
+            if constexpr (ti < PVT) {
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks)
+                    op[q][ks] = fma(raw[q][ks][2], Lq[ks][2], fma(raw[q][ks][1], Lq[ks][1], raw[q][ks][0] * Lq[ks][0]));
+            } else if constexpr (tj < PVT) {
+                const bool ok = 16 * (ti - PVT) + j <= NV;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) op[q][ks] = ok ? raw[q][ks][0] : 0.0;
+            }
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
     static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
@@ -1629,45 +1709,40 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti < PVT) {
-                const int bc = 2 * tj + jb1;
-                double bop[3];
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const int br = 2 * ti + kb[ks];
-                    bool sw = false;                 // upper half of a diagonal tile: the transposed block
-                    int hi = br, lo = bc;
-                    if constexpr (ti == tj) { sw = br < bc; hi = sw ? bc : br; lo = sw ? br : bc; }
-                    const double* Hp = sH + (hf[ks] * D::NJPAIR + hi * (hi + 1) / 2 + lo) * 9 + (sw ? aa[ks] : 3 * aa[ks]);
-                    const int st = sw ? 3 : 1;
-                    bop[ks] = fma(Hp[2 * st], Lq[ks][2], fma(Hp[st], Lq[ks][1], Hp[0] * Lq[ks][0]));
-                }
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[ks], bop[ks], c, 0, 0, 0);
+                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[ks], op[q][ks], c, 0, 0, 0);
             } else if constexpr (tj < PVT) {
-                const int cr = 16 * (ti - PVT) + j;
-                const bool ok = cr <= NV;
-                const int crc = ok ? cr : NV;
-                double aop[3];
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const double v = sRb[((hf[ks] * (NV + 1) + crc) * HC + 2 * tj + kb[ks]) * 3 + aa[ks]];
-                    aop[ks] = ok ? v : 0.0;
-                }
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ks], Lc[ks], c, 0, 0, 0);
-            } else {
+                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(op[q][ks], Lc[ks], c, 0, 0, 0);
+            }
+        }
+        acc[q] = c;
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    // throttle x throttle tiles: all N - 1 operand pairs of a tile are requested before its chain starts
+    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+        constexpr TileTab<D> tab{};
+        constexpr int q = decltype(qcst)::value;
+        constexpr int t = q * D::NWAVES + W;
+        if constexpr (t < D::NTRI) {
+            constexpr int ti = tab.ti[t], tj = tab.tj[t];
+            if constexpr (ti >= PVT && tj >= PVT) {
                 const int cr = 16 * (ti - PVT) + j, cc = 16 * (tj - PVT) + j;
                 const bool okr = cr <= NV, okc = cc < NV && g == (cc & 3);
                 const double* Ap = sAc + (okr ? cr : NV) * (N - 1) * 4 + g;
                 const double* Tp = sJetT + (cc < NV ? cc : 0) * N + 1;
+                double av[N - 1], bv[N - 1];
 #pragma unroll
-                for (int ks = 0; ks < N - 1; ++ks) {
-                    const double av = Ap[4 * ks], bv = Tp[ks];
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(okr ? av : 0.0, okc ? bv : 0.0, c, 0, 0, 0);
-                }
+                for (int ks = 0; ks < N - 1; ++ks) { av[ks] = Ap[4 * ks]; bv[ks] = Tp[ks]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < N - 1; ++ks) { av[ks] = okr ? av[ks] : 0.0; bv[ks] = okc ? bv[ks] : 0.0; }
+                d4 c = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < N - 1; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
+                acc[q] = c;
             }
         }
-        acc[q] = c;
     });
 }
 
@@ -1872,6 +1947,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         VS_TOC(1);
         p1s_contract<D>(smem, tid);
         __syncthreads();
+        VS_TOC(3);
         switch (wave) {
             case 0: p1s_entries<D, TPW, 0>(acc, smem, lane); break;
             case 1: p1s_entries<D, TPW, 1>(acc, smem, lane); break;

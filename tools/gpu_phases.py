@@ -21,7 +21,7 @@ for wl, B in ((("hover", 256), ("takeoff", 256)) if len(_s.argv) > 1 else (("hov
     print(f"== {wl} batch {B}: total cycles/instance median {np.median(tot):.0f} (s_memtime ticks), span of launch {(st[:,9].max()-st[:,0].min())}")
     for i, n in enumerate(names):
         print(f"  {n:38s} median {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f}  share {100*np.median(d[:, i])/np.median(tot):5.1f}%")
-    sub = ["P1 recursion / chain (wave 0)", "P1 barrier wait", "P1 MFMA / entries", "P1 set-up", "start stamp (s_memrealtime)", "wall time, 10 ns ticks (s_memrealtime)"]
+    sub = ["P1 recursion / chain (wave 0)", "P1 barrier wait", "P1 MFMA / entries", "P1 set-up / contraction (structured form)", "start stamp (s_memrealtime)", "wall time, 10 ns ticks (s_memrealtime)"]
     for i, n in enumerate(sub):
         print(f"    {n:36s} median {np.median(st[:, 10 + i]):9.0f}")
     start = st[:, 14] - st[:, 14].min(); end = start + st[:, 15]
