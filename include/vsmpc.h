@@ -168,6 +168,16 @@ int vsmpc_linearize_batch(vsmpc_handle* h, const double* in, int batch, double* 
 #define VSMPC_KIN_OUT 57
 int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double* out, double* records);
 
+/* Options of vsmpc_kinematics_batch, per handle.
+ *   joint_selector[8] (or NULL = keep): robot joint index of every controlled joint, for the columns of Lambda_ang -- the
+ *       reference selects them by NAME (`controlledJoints` against Robot::getJointName, systemDynamicsVSMPC.cpp:57-66,
+ *       202-205).  Default 3..10, the shipped robot.  Lambda_lin keeps the reference's hard-coded offset 3 (:348).
+ *   constant_lambda: jointsLambdaOption "constant" (systemDynamicsVSMPC.cpp:186-200,329-337).  The caller then delivers
+ *       the CONFIGURE-TIME axes, arms and relative Jacobians; the JFRAME slot holds the relative Jacobians' TOP rows
+ *       (4 x (3x23)) and JCOM[0..3] the thrusts of getRobot() that scale the angular term (the linear term keeps
+ *       THRUST = getRobotReference()'s, as in the reference). */
+int vsmpc_set_kinematics_options(vsmpc_handle* h, const int* joint_selector, int constant_lambda);
+
 /* Debug/parity: the reference-ordered dense QP of ONE instance, assembled on the host from the
  * DEVICE linearisation exactly as IMPCProblem::update stacks it (IMPCProblem.cpp:150-194):
  * H[nVar*nVar], g[nVar], Ac[nCon*nVar] (row-major), lo[nCon], hi[nCon]. */

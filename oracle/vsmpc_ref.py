@@ -582,8 +582,12 @@ KIN_SIZE = 697
 KIN_JOINT_OFFSET = 3  # systemDynamicsVSMPC.cpp:348 (middleCols(3, 8)); the name-based selector of :202-205 picks the same columns
 
 
-def kinematics_terms(kin: np.ndarray):
-    """Lambda_lin,B (3x8), Lambda_ang,B (3x8) ["unfiltered" option, vs_mcp_config.xml:21], I_G (3x3)."""
+def kinematics_terms(kin: np.ndarray, selector=None, constant: bool = False):
+    """Lambda_lin,B (3x8), Lambda_ang,B (3x8), I_G (3x3).  Default: the "unfiltered" option (vs_mcp_config.xml:21) with
+    the shipped robot's controlled joints 3..10.  `selector`: robot joint index of every controlled joint for Lambda_ang
+    (name-based in the reference, systemDynamicsVSMPC.cpp:57-66,202-205; Lambda_lin is hard-coded to 3..10, :348).
+    `constant`: jointsLambdaOption "constant" (:186-200,329-337) -- the record then carries the configure-time axes, arms
+    and relative Jacobians, the relative Jacobians' top rows in the JFRAME slot and getRobot()'s thrusts in JCOM[0:4]."""
     nJ = KIN_NJ
     R = kin[KIN_WRB:KIN_WRB + 9].reshape(3, 3)
     T = kin[KIN_THRUST:KIN_THRUST + 4]
@@ -596,19 +600,21 @@ def kinematics_terms(kin: np.ndarray):
     r = kin[KIN_R:KIN_R + 3]
     lam_lin = np.zeros((3, nJ))
     lam_ang = np.zeros((3, nJ))
+    Tang = kin[KIN_JCOM:KIN_JCOM + 4] if constant else T
     for i in range(4):
         Sa = from_vec_to_skew(R.T @ axes[i])
-        lam_lin -= T[i] * Sa @ Jrel[i]                                       # systemDynamicsVSMPC.cpp:339-345
-        JrelCoM = R.T @ (Jfr[i] - Jcom)                                      # :208-226 (getRelativeJacobianCoM)
-        lam_ang -= T[i] * Sa @ JrelCoM                                       # :169-174
-        lam_ang -= T[i] * from_vec_to_skew(R.T @ arms[i]) @ Sa @ Jrel[i]     # :176-183
+        lam_lin -= T[i] * Sa @ Jrel[i]                                       # systemDynamicsVSMPC.cpp:329-345
+        JrelCoM = Jfr[i] if constant else R.T @ (Jfr[i] - Jcom)              # :188-190 | :208-226 (getRelativeJacobianCoM)
+        lam_ang -= Tang[i] * Sa @ JrelCoM                                    # :169-174 | :188-197
+        lam_ang -= Tang[i] * from_vec_to_skew(R.T @ arms[i]) @ Sa @ Jrel[i]  # :176-183 | :191-197
     X = np.zeros((6, 6))                                                     # iDynTree Transform::asAdjointTransform
     X[0:3, 0:3] = R
     X[0:3, 3:6] = from_vec_to_skew(r) @ R
     X[3:6, 3:6] = R
     inertia = (X.T @ Mb @ X)[3:6, 3:6]                                       # :128-130
     o = KIN_JOINT_OFFSET
-    return lam_lin[:, o:o + 8].copy(), lam_ang[:, o:o + 8].copy(), inertia
+    sel = list(range(o, o + 8)) if selector is None else [int(v) for v in selector]
+    return lam_lin[:, o:o + 8].copy(), lam_ang[:, sel].copy(), inertia
 
 
 def solve_instance(cfg: Config, inp: np.ndarray):

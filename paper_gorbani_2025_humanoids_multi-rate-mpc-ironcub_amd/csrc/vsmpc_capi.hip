@@ -18,6 +18,7 @@ struct vsmpc_handle {
     DevCfg dev;
     int variant;
     int form;        // condensing form of the solve kernel (vsmpc_set_kernel_form)
+    KinOpts kin;     // vsmpc_set_kinematics_options
     int device;
     int max_batch;
     int n_var, n_con, n_in, n_p;
@@ -164,6 +165,8 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     fill_devcfg(*cfg, h->dev);
     h->variant = variant;
     h->form = initial_kernel_form();
+    for (int i = 0; i < VSMPC_N_JOINTS; ++i) h->kin.sel[i] = 3 + i;   // the shipped robot: joints 3..10
+    h->kin.constant_lambda = 0;
     if (h->form == 1 && !variant_has_structured(variant)) h->form = 0;
     h->device = device;
     h->max_batch = max_batch;
@@ -459,7 +462,7 @@ int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double
     if (batch == 0) return VSMPC_OK;
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpy(h->d_kin, kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(launch_kinematics(h->d_kin, batch, h->d_kout, nullptr));
+    HIP_TRY(launch_kinematics(h->d_kin, batch, h->d_kout, h->kin, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_kout, size_t(batch) * VSMPC_KIN_OUT * sizeof(double), hipMemcpyDeviceToHost));
     if (records != nullptr) {  // patch the three fields of the input records (host side, layout bookkeeping only)
@@ -471,6 +474,17 @@ int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double
             memcpy(rec + VSMPC_IN_INERTIA, o + 48, 9 * sizeof(double));
         }
     }
+    return VSMPC_OK;
+}
+
+int vsmpc_set_kinematics_options(vsmpc_handle* h, const int* joint_selector, int constant_lambda) {
+    if (h == nullptr) return VSMPC_ERR_INVALID_ARG;
+    if (joint_selector != nullptr) {
+        for (int i = 0; i < VSMPC_N_JOINTS; ++i)
+            if (joint_selector[i] < 0 || joint_selector[i] >= VSMPC_KIN_NJ) return VSMPC_ERR_INVALID_ARG;
+        for (int i = 0; i < VSMPC_N_JOINTS; ++i) h->kin.sel[i] = joint_selector[i];
+    }
+    h->kin.constant_lambda = constant_lambda ? 1 : 0;
     return VSMPC_OK;
 }
 

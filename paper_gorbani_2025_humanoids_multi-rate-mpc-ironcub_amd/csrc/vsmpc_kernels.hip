@@ -2552,8 +2552,13 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
 //   computeLambdaAng          systemDynamicsVSMPC.cpp:159-206 ("unfiltered"), getRelativeJacobianCoM :208-226
 //   locked inertia I_G        systemDynamicsVSMPC.cpp:128-130 (iDynTree adjoint X = [R, S(r)R; 0, R])
 // ------------------------------------------------------------------------------------------------
+// Options (vsmpc_set_kinematics_options): `sel` = robot joint index of each controlled joint for Lambda_ang, which the
+// reference selects by NAME (systemDynamicsVSMPC.cpp:57-66,202-205; Lambda_lin keeps the reference's hard-coded column
+// offset 3, :348); `constant_lambda` = jointsLambdaOption "constant" (:186-200,329-337): axes, arms and relative Jacobians
+// are the configure-time ones, the angular term uses the relative Jacobian's own top rows (delivered in the JFRAME slot)
+// instead of R^T (J_frame - J_CoM) and the thrusts of getRobot() (delivered in JCOM[0..3]).
 __global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict__ kin, int batch,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, KinOpts opts) {
     __shared__ __attribute__((aligned(16))) double s[VSMPC_KIN_SIZE + 1];
     __shared__ double sRa[12], sRr[12];  // R^T a_i, R^T r_i
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -2579,13 +2584,13 @@ __global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict
         (which ? sRr : sRa)[e] = val;
     }
     __syncthreads();
-    constexpr int NJq = VSMPC_KIN_NJ, OFF = 3;  // controlled joints = robot joints 3..10 (systemDynamicsVSMPC.cpp:348)
+    constexpr int NJq = VSMPC_KIN_NJ, OFF = 3;  // Lambda_lin: robot joints 3..10 (systemDynamicsVSMPC.cpp:348)
     double res = 0.0;
     if (lane < 48) {
         const bool ang = lane >= 24;
-        const int e = lane % 24, r = e >> 3, col = OFF + (e & 7);
+        const int e = lane % 24, r = e >> 3, col = ang ? opts.sel[e & 7] : OFF + (e & 7);
         for (int i = 0; i < 4; ++i) {
-            const double T = s[VSMPC_KIN_THRUST + i];
+            const double T = (ang && opts.constant_lambda) ? s[VSMPC_KIN_JCOM + i] : s[VSMPC_KIN_THRUST + i];
             const double* a = sRa + 3 * i;
             const double* Jrel = s + VSMPC_KIN_JREL + i * 3 * NJq;
             // w = S(a) * Jrel[:, col]  (skew: FlightControlUtils.cpp:77-85)
@@ -2597,9 +2602,10 @@ __global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict
                 const double* Jf = s + VSMPC_KIN_JFRAME + i * 3 * NJq;
                 const double* Jc = s + VSMPC_KIN_JCOM;
                 const double d0 = Jf[col] - Jc[col], d1 = Jf[NJq + col] - Jc[NJq + col], d2 = Jf[2 * NJq + col] - Jc[2 * NJq + col];
-                const double g0 = R[0] * d0 + R[3] * d1 + R[6] * d2;  // R^T (J_frame - J_CoM)
-                const double g1 = R[1] * d0 + R[4] * d1 + R[7] * d2;
-                const double g2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+                double g0 = R[0] * d0 + R[3] * d1 + R[6] * d2;  // R^T (J_frame - J_CoM)
+                double g1 = R[1] * d0 + R[4] * d1 + R[7] * d2;
+                double g2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+                if (opts.constant_lambda) { g0 = Jf[col]; g1 = Jf[NJq + col]; g2 = Jf[2 * NJq + col]; }
                 const double u0 = -a[2] * g1 + a[1] * g2, u1 = a[2] * g0 - a[0] * g2, u2 = -a[1] * g0 + a[0] * g1;
                 const double* q = sRr + 3 * i;  // S(R^T r_i) * w
                 const double z0 = -q[2] * w1 + q[1] * w2, z1 = q[2] * w0 - q[0] * w2, z2 = -q[1] * w0 + q[0] * w1;
@@ -2624,8 +2630,8 @@ __global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict
     if (lane < VSMPC_KIN_OUT) out[size_t(b) * VSMPC_KIN_OUT + lane] = res;
 }
 
-hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipStream_t stream) {
-    hipLaunchKernelGGL(kinematics_kernel, dim3(batch), dim3(64), 0, stream, d_kin, batch, d_out);
+hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, const KinOpts& opts, hipStream_t stream) {
+    hipLaunchKernelGGL(kinematics_kernel, dim3(batch), dim3(64), 0, stream, d_kin, batch, d_out, opts);
     return hipGetLastError();
 }
 

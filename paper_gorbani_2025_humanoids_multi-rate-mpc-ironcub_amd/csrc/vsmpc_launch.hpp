@@ -28,7 +28,11 @@ hipError_t launch_solve(int variant, int form, const DevCfg& cfg, const double* 
 hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
                             double* Bt, double* c, hipStream_t stream);
 
-hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, hipStream_t stream);
+struct KinOpts {
+    int sel[VSMPC_N_JOINTS];   // robot joint index of every controlled joint (Lambda_ang columns)
+    int constant_lambda;       // jointsLambdaOption "constant"
+};
+hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, const KinOpts& opts, hipStream_t stream);
 
 // closed-loop rollout (vsmpc_rollout.hip)
 struct RolloutDev {

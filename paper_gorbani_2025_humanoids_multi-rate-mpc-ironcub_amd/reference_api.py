@@ -77,15 +77,29 @@ class QPInput:
     def getAlphaGravity(self): return self._alphaGravity
 
 
-def _param(handler, name, default=None):
-    if hasattr(handler, "getParameter"):
+_BLF_GETTERS = {"int": "get_parameter_int", "float": "get_parameter_float", "bool": "get_parameter_bool",
+                "str": "get_parameter_string", "vec": "get_parameter_vector_float", "strvec": "get_parameter_vector_string"}
+
+
+def _param(handler, name, default=None, kind=None):
+    """One key of a parameters handler: BLF's Python handler (get_parameter_int / _float / _bool / _string /
+    _vector_float / _vector_string, as src/variable_sampling_mpc.py:38-40 uses it), the C++ spelling getParameter(name),
+    or a mapping."""
+    v = None
+    blf = _BLF_GETTERS.get(kind or "", None)
+    if blf is not None and hasattr(handler, blf):
+        try:
+            v = getattr(handler, blf)(name)
+        except (ValueError, KeyError, RuntimeError):     # BLF raises when the key is missing
+            v = None
+    elif hasattr(handler, "getParameter"):
         v = handler.getParameter(name)
-        if isinstance(v, tuple):                         # BLF python handlers return (ok, value)
+        if isinstance(v, tuple):                         # (ok, value)
             ok, v = v
             if not ok:
                 v = None
-    else:
-        v = handler.get(name) if hasattr(handler, "get") else None
+    elif hasattr(handler, "get"):
+        v = handler.get(name)
     if v is None:
         if default is None:
             raise KeyError(f"Parameter '{name}' not found in the config file.")
@@ -94,8 +108,9 @@ def _param(handler, name, default=None):
 
 
 def _group(handler, name):
-    if hasattr(handler, "getGroup"):
-        return handler.getGroup(name)
+    for getter in ("get_group", "getGroup"):
+        if hasattr(handler, getter):
+            return getattr(handler, getter)(name)
     return handler[name]
 
 
@@ -158,20 +173,25 @@ class VariableSamplingMPC:
         try:
             h = _group(parametersHandler, "VS_MPC_CONFIG") if _has_group(parametersHandler, "VS_MPC_CONFIG") else parametersHandler
             cfg = L.MPCConfig(
-                n_iter=int(_param(h, "nIter")), n_iter_small=int(_param(h, "nIterSmall")),
-                control_horizon=int(_param(h, "controlHorizon")), use_jet_dynamic=bool(_param(h, "useJetDynamic")),
-                period_mpc=float(_param(h, "periodMPC")), period_small=float(_param(h, "periodMPCSmallSteps")),
-                period_large=float(_param(h, "periodMPCLargeSteps")),
-                w_com_pos=tuple(_param(h, "weightCoMPos")), w_com_pos_err=tuple(_param(h, "weightCoMPosError")),
-                w_lin_mom=tuple(_param(h, "weightLinMom")), w_rpy=tuple(_param(h, "weightRPY")),
-                w_rpy_err=tuple(_param(h, "weightRPYError")), w_ang_mom=tuple(_param(h, "weightAngMom")),
-                w_delta_joint=tuple(_param(h, "weightDeltaJoint")), w_throttle=float(_param(h, "weightThrottle")),
-                w_initial_throttle=float(_param(h, "weightInitialThrottle")),
-                w_reg_joint_pos=float(_param(h, "weightRegularizationJointPos")),
-                throttle_min=float(_param(h, "throttleMin")), throttle_max=float(_param(h, "throttleMax")))
-            self._useEstimatedThrust = bool(_param(h, "useEstimatedThrust", True))
-            if str(_param(h, "jointsLambdaOption", "unfiltered")) != "unfiltered":
-                raise ValueError("jointsLambdaOption 'constant' is not built (the shipped configuration is 'unfiltered')")
+                n_iter=int(_param(h, "nIter", kind="int")), n_iter_small=int(_param(h, "nIterSmall", kind="int")),
+                control_horizon=int(_param(h, "controlHorizon", kind="int")),
+                use_jet_dynamic=bool(_param(h, "useJetDynamic", kind="bool")),
+                period_mpc=float(_param(h, "periodMPC", kind="float")),
+                period_small=float(_param(h, "periodMPCSmallSteps", kind="float")),
+                period_large=float(_param(h, "periodMPCLargeSteps", kind="float")),
+                w_com_pos=tuple(_param(h, "weightCoMPos", kind="vec")), w_com_pos_err=tuple(_param(h, "weightCoMPosError", kind="vec")),
+                w_lin_mom=tuple(_param(h, "weightLinMom", kind="vec")), w_rpy=tuple(_param(h, "weightRPY", kind="vec")),
+                w_rpy_err=tuple(_param(h, "weightRPYError", kind="vec")), w_ang_mom=tuple(_param(h, "weightAngMom", kind="vec")),
+                w_delta_joint=tuple(_param(h, "weightDeltaJoint", kind="vec")), w_throttle=float(_param(h, "weightThrottle", kind="float")),
+                w_initial_throttle=float(_param(h, "weightInitialThrottle", kind="float")),
+                w_reg_joint_pos=float(_param(h, "weightRegularizationJointPos", kind="float")),
+                throttle_min=float(_param(h, "throttleMin", kind="float")), throttle_max=float(_param(h, "throttleMax", kind="float")))
+            self._useEstimatedThrust = bool(_param(h, "useEstimatedThrust", True, kind="bool"))
+            option = str(_param(h, "jointsLambdaOption", "unfiltered", kind="str"))
+            if option not in ("unfiltered", "constant"):             # systemDynamicsVSMPC.cpp:33-46
+                raise ValueError("Parameter 'jointsLambdaOption' should be 'unfiltered' or 'constant'.")
+            self._constantLambda = option == "constant"
+            self._controlledJoints = list(_param(h, "controlledJoints", [], kind="strvec"))
             tm, pt = _group(h, "TRAJECTORY_MANAGER"), _group(h, "POSITION_TRAJECTORY")
             self._alpha = _Track({"alphaGravity": np.asarray(tm["alphaGravity"], float).reshape(-1)}, int(tm.get("fps", 10)),
                                  int(1 / cfg.period_mpc))                                    # systemDynamicsVSMPC.cpp:272
@@ -186,6 +206,20 @@ class VariableSamplingMPC:
         self._solver = BatchedVSMPC(cfg, device=self._device, max_batch=1)
         self._ratio = cfg.ratio
         robot = qpInput.getRobot()
+        # controlled joints by NAME where the robot can name its joints (variableSamplingMPC.cpp:47-58,
+        # costsVSMPC.cpp:539-550, systemDynamicsVSMPC.cpp:57-66); the shipped robot has them at 3..10
+        self._sel = list(range(JOINT_OFFSET, JOINT_OFFSET + 8))
+        if self._controlledJoints and hasattr(robot, "getJointName"):
+            names = [robot.getJointName(i) for i in range(N_ROBOT_JOINTS)]
+            self._sel = [names.index(n) for n in self._controlledJoints]
+            if len(self._sel) != 8:
+                print("[VariableSamplingMPC::configure] 'controlledJoints' must name the 8 controlled joints")
+                return False
+        self._solver.set_kinematics_options(self._sel, self._constantLambda)
+        if self._constantLambda:                                     # systemDynamicsVSMPC.cpp:53-55,276-277
+            self._relJacInit = [np.array(j, dtype=float) for j in robot.getRelativeJacobianJetsBodyFrame()]
+            self._axesInit = np.array(robot.getMatrixOfJetAxes(), dtype=float)
+            self._armsInit = np.array(robot.getMatrixOfJetArms(), dtype=float)
         # plugin members set at configure time
         self._m_initialCoMPos = np.array(robot.getPositionCoM(), dtype=float)                # costsVSMPC.cpp:101
         self._m_initialRPY = _rpy_of(_base_rotation(robot))                                # costsVSMPC.cpp:102
@@ -194,7 +228,7 @@ class VariableSamplingMPC:
         self._m_nTurns = np.zeros(3)
         q = np.array(robot.getJointPos(), dtype=float)
         self._m_jointsPositionReference = q.copy()                                           # variableSamplingMPC.cpp:59-60
-        self._m_jointPosReference = q[JOINT_OFFSET:JOINT_OFFSET + 8].copy()                  # costsVSMPC.cpp:539-550
+        self._m_jointPosReference = q[self._sel].copy()                                      # costsVSMPC.cpp:539-550
         ncol = cfg.n_ref_cols
         col = self._reference_column(robot)
         self._window = np.tile(col[None, :], (ncol, 1))                                      # costsVSMPC.cpp:103-113
@@ -228,7 +262,7 @@ class VariableSamplingMPC:
             self._thrustReference = fm[0, L.FM_THRUST:L.FM_THRUST + 4].copy()
             self._thrustDotReference = fm[0, L.FM_THRUSTDOT:L.FM_THRUSTDOT + 4].copy()
             self._finalState = x[0, 26 * self.cfg.n_iter:26 * (self.cfg.n_iter + 1)].copy()
-            self._m_jointsPositionReference[JOINT_OFFSET:JOINT_OFFSET + 8] += self._deltaJoints   # :104-108
+            self._m_jointsPositionReference[self._sel] += self._deltaJoints                  # :104-108
         return True                                                                           # :111
 
     # ------------------------------------------------------------------ getters (variableSamplingMPC.cpp:114-227)
@@ -261,29 +295,37 @@ class VariableSamplingMPC:
             rpy = _rpy_of(R)
             W = np.array([[1.0, 0.0, -math.sin(rpy[1])], [0.0, math.cos(rpy[0]), math.cos(rpy[1]) * math.sin(rpy[0])],
                           [0.0, -math.sin(rpy[0]), math.cos(rpy[0]) * math.cos(rpy[1])]])
-            col[9:12] = self._locked_inertia_host(robot) @ W @ rpy_dot
+            col[9:12] = self._locked_inertia(robot) @ W @ rpy_dot
         return col
 
-    @staticmethod
-    def _locked_inertia_host(robot):
-        R = np.asarray(_base_rotation(robot), float).reshape(3, 3)
-        r = np.asarray(robot.getPositionCoM(), float) - np.asarray(robot.getBasePosition(), float)
-        S = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
-        X = np.vstack([S @ R, R])
-        return X.T @ np.asarray(robot.getMassMatrix(), float)[0:6, 0:6] @ X
+    def _locked_inertia(self, robot):
+        """I_G of getRobot() (costsVSMPC.cpp:266-286) on the device: a kinematics record that carries only what I_G needs."""
+        k = np.zeros(L.KIN_SIZE)
+        k[L.KIN_WRB:L.KIN_WRB + 9] = np.asarray(_base_rotation(robot), float).reshape(-1)
+        k[L.KIN_MB:L.KIN_MB + 36] = np.asarray(robot.getMassMatrix(), float)[0:6, 0:6].reshape(-1)
+        k[L.KIN_R:L.KIN_R + 3] = np.asarray(robot.getPositionCoM(), float) - np.asarray(robot.getBasePosition(), float)
+        return self._solver.kinematics(k[None, :])[2][0]
 
-    def _kin_record(self, robot):
-        """raw Robot quantities in the VSMPC_KIN_* layout (include/vsmpc.h) for vsmpc_kinematics_batch."""
+    def _kin_record(self, robot, plant=None):
+        """raw Robot quantities in the VSMPC_KIN_* layout (include/vsmpc.h) for vsmpc_kinematics_batch; `robot` is
+        getRobotReference(), `plant` getRobot() (its thrusts scale the angular term of the 'constant' option)."""
         k = np.zeros(L.KIN_SIZE)
         k[L.KIN_WRB:L.KIN_WRB + 9] = np.asarray(_base_rotation(robot), float).reshape(-1)
         k[L.KIN_THRUST:L.KIN_THRUST + 4] = robot.getJetThrusts()
-        k[L.KIN_AXES:L.KIN_AXES + 12] = np.asarray(robot.getMatrixOfJetAxes(), float).reshape(-1)       # 4 x 3
-        k[L.KIN_ARMS:L.KIN_ARMS + 12] = np.asarray(robot.getMatrixOfJetArms(), float).reshape(-1)       # 4 x 3
-        jrel = robot.getRelativeJacobianJetsBodyFrame()                                                  # 4 x (6 x 23)
-        k[L.KIN_JREL:L.KIN_JREL + 276] = np.stack([np.asarray(j, float)[3:6, :] for j in jrel]).reshape(-1)
-        jac = [robot.getJacobian(name) for name in robot.getJetsList()]             # systemDynamicsVSMPC.cpp:167,208-212
-        k[L.KIN_JFRAME:L.KIN_JFRAME + 276] = np.stack([np.asarray(j, float)[0:3, 6:29] for j in jac]).reshape(-1)
-        k[L.KIN_JCOM:L.KIN_JCOM + 69] = np.asarray(robot.getJacobianCoM(), float)[0:3, 6:29].reshape(-1)
+        if self._constantLambda:                            # configure-time geometry (systemDynamicsVSMPC.cpp:186-200,329-337)
+            k[L.KIN_AXES:L.KIN_AXES + 12] = self._axesInit.reshape(-1)
+            k[L.KIN_ARMS:L.KIN_ARMS + 12] = self._armsInit.reshape(-1)
+            k[L.KIN_JREL:L.KIN_JREL + 276] = np.stack([j[3:6, :] for j in self._relJacInit]).reshape(-1)
+            k[L.KIN_JFRAME:L.KIN_JFRAME + 276] = np.stack([j[0:3, :] for j in self._relJacInit]).reshape(-1)
+            k[L.KIN_JCOM:L.KIN_JCOM + 4] = (plant if plant is not None else robot).getJetThrusts()
+        else:
+            k[L.KIN_AXES:L.KIN_AXES + 12] = np.asarray(robot.getMatrixOfJetAxes(), float).reshape(-1)   # 4 x 3
+            k[L.KIN_ARMS:L.KIN_ARMS + 12] = np.asarray(robot.getMatrixOfJetArms(), float).reshape(-1)   # 4 x 3
+            jrel = robot.getRelativeJacobianJetsBodyFrame()                                              # 4 x (6 x 23)
+            k[L.KIN_JREL:L.KIN_JREL + 276] = np.stack([np.asarray(j, float)[3:6, :] for j in jrel]).reshape(-1)
+            jac = [robot.getJacobian(name) for name in robot.getJetsList()]         # systemDynamicsVSMPC.cpp:167,208-212
+            k[L.KIN_JFRAME:L.KIN_JFRAME + 276] = np.stack([np.asarray(j, float)[0:3, 6:29] for j in jac]).reshape(-1)
+            k[L.KIN_JCOM:L.KIN_JCOM + 69] = np.asarray(robot.getJacobianCoM(), float)[0:3, 6:29].reshape(-1)
         k[L.KIN_MB:L.KIN_MB + 36] = np.asarray(robot.getMassMatrix(), float)[0:6, 0:6].reshape(-1)
         k[L.KIN_R:L.KIN_R + 3] = np.asarray(robot.getPositionCoM(), float) - np.asarray(robot.getBasePosition(), float)
         return k
@@ -306,19 +348,19 @@ class VariableSamplingMPC:
         rec[L.IN_XREF:L.IN_XREF + 12 * cfg.n_ref_cols] = self._window.reshape(-1)
         # --- JointPositionRegularizationCost (costsVSMPC.cpp:574-589)
         qcmd = np.asarray(qp.getOutputQPJointsPosition(), float)
-        rec[L.IN_QERR:L.IN_QERR + 8] = qcmd[JOINT_OFFSET:JOINT_OFFSET + 8] - self._m_jointPosReference
+        rec[L.IN_QERR:L.IN_QERR + 8] = qcmd[self._sel] - self._m_jointPosReference
         # --- dynamics (systemDynamicsVSMPC.cpp:79-103,288-319,384-429); the kinematics terms on the device
         R = np.asarray(_base_rotation(ref), float).reshape(3, 3)
         rec[L.IN_MASS] = float(np.float32(ref.getTotalMass()))                               # Robot.h:338 keeps a float
         rec[L.IN_WRB:L.IN_WRB + 9] = R.reshape(-1)
-        rec[L.IN_OMEGA:L.IN_OMEGA + 3] = R.T @ np.asarray(ref.getBaseAngVel(), float)   # systemDynamicsVSMPC.cpp:108,325
+        rec[L.IN_OMEGA:L.IN_OMEGA + 3] = R.T @ np.asarray(robot.getBaseAngVel(), float)  # m_robot's: systemDynamicsVSMPC.cpp:108,325
         alpha = float(self._alpha.current("alphaGravity")[0])                                # :308-311: use, then advance
         qp.setAlphaGravity(alpha)
         self._alpha.advance()
         rec[L.IN_ALPHA] = alpha
         rec[L.IN_GRAV:L.IN_GRAV + 3] = ref.getGravity()
         rec[L.IN_AMOM:L.IN_AMOM + 24] = np.asarray(ref.getMatrixAmomJets(True), float).reshape(-1)
-        Llin, Lang, IG = self._solver.kinematics(self._kin_record(ref)[None, :])
+        Llin, Lang, IG = self._solver.kinematics(self._kin_record(ref, robot)[None, :])
         rec[L.IN_LLIN:L.IN_LLIN + 24] = Llin[0].reshape(-1)
         rec[L.IN_LANG:L.IN_LANG + 24] = Lang[0].reshape(-1)
         rec[L.IN_INERTIA:L.IN_INERTIA + 9] = IG[0].reshape(-1)
@@ -326,7 +368,7 @@ class VariableSamplingMPC:
         rec[L.IN_PREF:L.IN_PREF + 3] = qp.getPosCoMReference()
         rec[L.IN_RPYINIT:L.IN_RPYINIT + 3] = self._m_rpyInit
         if self._useEstimatedThrust:                                                         # :401-409
-            T0, Td0 = np.asarray(ref.getJetThrusts(), float), np.asarray(qp.getEstimatedThrustDot(), float)
+            T0, Td0 = np.asarray(robot.getJetThrusts(), float), np.asarray(qp.getEstimatedThrustDot(), float)   # m_robot's (:403)
         else:
             T0, Td0 = np.asarray(qp.getThrustDesMPC(), float), np.asarray(qp.getThrustDotDesMPC(), float)
         rec[L.IN_T0:L.IN_T0 + 4] = T0
@@ -362,5 +404,5 @@ class VariableSamplingMPC:
 def _has_group(handler, name):
     try:
         return _group(handler, name) is not None
-    except (KeyError, TypeError, AttributeError):
+    except (KeyError, TypeError, AttributeError, ValueError, RuntimeError):   # (BLF raises when the group is missing)
         return False

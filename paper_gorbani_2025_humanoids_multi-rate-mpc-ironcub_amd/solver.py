@@ -151,6 +151,15 @@ class BatchedVSMPC:
                    "vsmpc_kinematics_batch")
         return out[:, 0:24].reshape(-1, 3, 8), out[:, 24:48].reshape(-1, 3, 8), out[:, 48:57].reshape(-1, 3, 3)
 
+    def set_kinematics_options(self, joint_selector=None, constant_lambda: bool = False):
+        """vsmpc_set_kinematics_options: robot joint indices of the controlled joints (Lambda_ang columns; the
+        reference selects them by name) and jointsLambdaOption 'constant'."""
+        sel = None
+        if joint_selector is not None:
+            sel = (ctypes.c_int * 8)(*[int(v) for v in joint_selector])
+        _lib.check(self.lib.vsmpc_set_kinematics_options(self._h, sel, 1 if constant_lambda else 0),
+                   "vsmpc_set_kinematics_options")
+
     def phase_cycles(self, inputs: np.ndarray) -> np.ndarray:
         """Diagnostic build only: per-instance s_memtime stamps at the phase boundaries, [batch, 16]."""
         inputs = np.ascontiguousarray(inputs, dtype=np.float64)

@@ -24,15 +24,28 @@ def test_header_compiles_and_links(tmp_path, solver_mod):
     build_driver(tmp_path, solver_mod)
 
 
+def test_reference_surface_template_compiles_and_links(tmp_path, solver_mod):
+    """include/VariableSamplingMPC.hpp's VariableSamplingMPCT against provider classes with the members of Robot.h /
+    QPInput.h / IParametersHandler (tests/cpp/reference_surface_driver.cpp); run on the GPU by
+    tests/test_gpu_reference_surface.py."""
+    exe = str(tmp_path / "reference_surface_driver")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "reference_surface_driver.cpp"), "-o", exe,
+           "-L", PKG_DIR, "-lvsmpc", f"-Wl,-rpath,{PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
 def test_tick_state_machine_semantics(tmp_path):
-    """Pure host logic of TickState, checked through a tiny C++ program (no GPU, no library)."""
+    """Pure host logic of TickMachine's hold counter and RPY unwrap, checked through a tiny C++ program (no GPU, no
+    library: the members that call the C-ABI are templates and stay uninstantiated)."""
     src = tmp_path / "tick.cpp"
     src.write_text(r'''
 #include <cstdio>
 #include "VariableSamplingMPC.hpp"
 int main() {
     vsmpc_config c{}; c.period_large = 0.1; c.period_small = 0.005;
-    vsmpc_host::TickState t; double r0[3] = {3.0, 0, 0}; t.configure(c, r0);
+    vsmpc_host::TickMachine t; double r0[3] = {3.0, 0, 0}; t.initCounters(c, r0);
     int free_ticks = 0; for (int k = 0; k < 100; ++k) { bool h = t.nextHoldFlag(); if (!h) { ++free_ticks; std::printf("%d ", k); } }
     std::printf("| %d |", free_ticks);
     double in1[3] = {-3.1, 0, 0}, out[3]; t.unwrapRPY(in1, out); std::printf(" %.6f", out[0]);   // 3.0 -> -3.1 wraps up

@@ -389,6 +389,28 @@ def test_kinematics_terms_match_oracle(mpc, ref, synth, layout):
     assert (st == layout.STATUS_SOLVED).all()
 
 
+def test_kinematics_options_match_oracle(solver_mod, ref, layout):
+    """vsmpc_set_kinematics_options: Lambda_ang columns selected by (name-derived) robot joint index
+    (systemDynamicsVSMPC.cpp:57-66,202-205) and jointsLambdaOption 'constant' (:186-200,329-337)."""
+    rng = np.random.default_rng(11)
+    kin = rng.normal(size=(9, layout.KIN_SIZE))
+    for b in range(len(kin)):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        kin[b, layout.KIN_WRB:layout.KIN_WRB + 9] = (q * np.sign(np.linalg.det(q))).reshape(-1)
+    m = solver_mod.BatchedVSMPC(layout.paper_config(), device=0, max_batch=16)
+    try:
+        for sel, const in (([5, 3, 12, 6, 7, 20, 9, 0], False), (list(range(3, 11)), True), ([22, 1, 2, 4, 8, 16, 10, 11], True)):
+            m.set_kinematics_options(sel, const)
+            Llin, Lang, IG = m.kinematics(kin)
+            for b in range(len(kin)):
+                l1, l2, ig = ref.kinematics_terms(kin[b], selector=sel, constant=const)
+                assert relerr(Llin[b], l1) < 1e-13 and relerr(Lang[b], l2) < 1e-13 and relerr(IG[b], ig) < 1e-13
+        with pytest.raises(Exception):
+            m.set_kinematics_options([0, 1, 2, 3, 4, 5, 6, 23], False)      # not a robot joint
+    finally:
+        m.close()
+
+
 @pytest.fixture(scope="module")
 def mpc2x(solver_mod, layout):
     m = solver_mod.BatchedVSMPC(layout.horizon2x_config(), device=0, max_batch=256)

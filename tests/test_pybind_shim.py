@@ -25,9 +25,8 @@ def shim(solver_mod):
     path = build.build_bindings()
     if path is None:
         pytest.skip("pybind11 not available")
-    sys.path.insert(0, os.path.dirname(path))
     import torch  # noqa: F401  (first: libvsmpc.so must bind to the HIP runtime torch brings along, see _lib.py)
-    return importlib.import_module("bindingsMPC")
+    return importlib.import_module(PKG + ".bindingsMPC")
 
 
 def test_shim_surface(shim):
@@ -39,7 +38,7 @@ def test_shim_surface(shim):
     bad = dict(PARAMS)
     del bad["nIter"]
     with pytest.raises(Exception) as e:
-        shim.VariableSamplingMPC().configure(bad)
+        shim.VariableSamplingMPC().configure(bad, np.zeros(23), np.zeros(3))
     assert "nIter" in str(e.value)                         # "Parameter 'nIter' not found" like the reference's yError
 
 
