@@ -178,6 +178,52 @@ int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double
  *       THRUST = getRobotReference()'s, as in the reference). */
 int vsmpc_set_kinematics_options(vsmpc_handle* h, const int* joint_selector, int constant_lambda);
 
+/* Batched kinematics provider: what the reference's Robot::setState caches for the path
+ * (utils/src/Robot.cpp:198-335, getJacobian :505-514) on a SIMPLIFIED tree handed over as plain arrays: a floating base,
+ * 8 revolute joints (joint j moves body j + 1; parents precede children), 4 jet frames.  iDynTree's conventions: MIXED
+ * velocity representation, free-floating Jacobians [linear; angular] x [base 6 | joints].  The reference uses iDynTree
+ * on the iRonCub URDF, neither of which is in this image: parity of this row is unpinned (oracle/robot_tree_ref.py). */
+#define VSMPC_TREE_NB 9
+#define VSMPC_TREE_NJ 8
+typedef struct {
+    int parent[VSMPC_TREE_NB];                 /* parent body (parent[0] = -1: the floating base) */
+    int robot_joint[VSMPC_TREE_NJ];            /* index of tree joint j among the robot's 23 joints (Jacobian column) */
+    double joint_axis[3 * VSMPC_TREE_NJ];      /* in the parent body's frame */
+    double joint_origin[3 * VSMPC_TREE_NJ];    /* in the parent body's frame; the child frame sits there */
+    double mass[VSMPC_TREE_NB];
+    double com[3 * VSMPC_TREE_NB];             /* body frame */
+    double inertia[6 * VSMPC_TREE_NB];         /* about the body CoM, body axes: xx xy xz yy yz zz */
+    int jet_body[VSMPC_N_THRUSTS];
+    double jet_origin[3 * VSMPC_N_THRUSTS];    /* body frame */
+    double jet_axis[3 * VSMPC_N_THRUSTS];      /* thrust force direction, body frame (m_jetsAxesLocalFrames, Robot.cpp:256) */
+    double gravity[3];
+} vsmpc_tree;
+/* state record per instance */
+#define VSMPC_RS_P 0      /*  3 base position (world)                         */
+#define VSMPC_RS_R 3      /*  9 wR_b row-major                                 */
+#define VSMPC_RS_V 12     /*  3 base linear velocity (world, MIXED)           */
+#define VSMPC_RS_W 15     /*  3 base angular velocity (world)                 */
+#define VSMPC_RS_Q 18     /*  8 joint positions                               */
+#define VSMPC_RS_QD 26    /*  8 joint velocities                              */
+#define VSMPC_RS_T 34     /*  4 jet thrusts                                   */
+#define VSMPC_RS_SIZE 38
+/* Robot-level outputs per instance */
+#define VSMPC_RO_COM 0    /*  3 getPositionCoM                                 */
+#define VSMPC_RO_MOM 3    /*  6 getMomentum(false): centroidal, world axes     */
+#define VSMPC_RO_MOMB 9   /*  6 getMomentum(true)                              */
+#define VSMPC_RO_MASS 15  /*  1 getTotalMass                                   */
+#define VSMPC_RO_AMOM 16  /* 24 getMatrixAmomJets(false) 6x4 row-major         */
+#define VSMPC_RO_AMOMB 40 /* 24 getMatrixAmomJets(true)                        */
+#define VSMPC_RO_RPY 64   /*  3 getBasePose().getRotation().asRPY()            */
+#define VSMPC_RO_SIZE 67
+/* state[batch][VSMPC_RS_SIZE] -> kin[batch][VSMPC_KIN_SIZE] (the record vsmpc_kinematics_batch reads; NULL = not wanted),
+ * robot[batch][VSMPC_RO_SIZE] (NULL = not wanted) and, when `records` (batch input records of this handle's size) is
+ * given, the fields update() pulls out of the Robot patched in place: X0 position / momentum / RPY / thrusts, MASS, WRB,
+ * OMEGA, GRAV, AMOM, RPY, T0, and -- through the kinematics kernel on the device, no host round trip -- LLIN, LANG,
+ * INERTIA.  Everything else of the record (references, throttle feedback, hold flag) stays the caller's. */
+int vsmpc_provider_batch(vsmpc_handle* h, const vsmpc_tree* tree, const double* state, int batch, double* kin,
+                         double* robot, double* records);
+
 /* Debug/parity: the reference-ordered dense QP of ONE instance, assembled on the host from the
  * DEVICE linearisation exactly as IMPCProblem::update stacks it (IMPCProblem.cpp:150-194):
  * H[nVar*nVar], g[nVar], Ac[nCon*nVar] (row-major), lo[nCon], hi[nCon]. */

@@ -477,6 +477,38 @@ int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double
     return VSMPC_OK;
 }
 
+int vsmpc_provider_batch(vsmpc_handle* h, const vsmpc_tree* tree, const double* state, int batch, double* kin,
+                         double* robot, double* records) {
+    if (h == nullptr || tree == nullptr || state == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
+    if (batch == 0) return VSMPC_OK;
+    if (tree->parent[0] != -1) return VSMPC_ERR_INVALID_ARG;
+    for (int b = 1; b < VSMPC_TREE_NB; ++b)
+        if (tree->parent[b] < 0 || tree->parent[b] >= b) return VSMPC_ERR_INVALID_ARG;      // parents precede children
+    for (int j = 0; j < VSMPC_TREE_NJ; ++j)
+        if (tree->robot_joint[j] < 0 || tree->robot_joint[j] >= VSMPC_KIN_NJ) return VSMPC_ERR_INVALID_ARG;
+    for (int i = 0; i < VSMPC_N_THRUSTS; ++i)
+        if (tree->jet_body[i] < 0 || tree->jet_body[i] >= VSMPC_TREE_NB) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    // scratch: the state records go through d_lin (1014 doubles per instance), the Robot-level outputs through d_x
+    // (n_var >= 67 doubles per instance), the kinematics record through d_kin
+    double* d_state = h->d_lin;
+    double* d_robot = h->d_x;   // n_var >= 67 doubles per instance
+    HIP_TRY(hipMemcpy(d_state, state, size_t(batch) * VSMPC_RS_SIZE * sizeof(double), hipMemcpyHostToDevice));
+    if (records != nullptr)
+        HIP_TRY(hipMemcpy(h->d_in, records, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(launch_provider(*tree, d_state, batch, h->d_kin, d_robot, records != nullptr ? h->d_in : nullptr, h->n_in, nullptr));
+    if (records != nullptr) HIP_TRY(launch_kinematics_patch(h->d_kin, batch, h->d_in, h->n_in, h->kin, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    if (kin != nullptr)
+        HIP_TRY(hipMemcpy(kin, h->d_kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyDeviceToHost));
+    if (robot != nullptr)
+        HIP_TRY(hipMemcpy(robot, d_robot, size_t(batch) * VSMPC_RO_SIZE * sizeof(double), hipMemcpyDeviceToHost));
+    if (records != nullptr)
+        HIP_TRY(hipMemcpy(records, h->d_in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyDeviceToHost));
+    return VSMPC_OK;
+}
+
 int vsmpc_set_kinematics_options(vsmpc_handle* h, const int* joint_selector, int constant_lambda) {
     if (h == nullptr) return VSMPC_ERR_INVALID_ARG;
     if (joint_selector != nullptr) {

@@ -2627,7 +2627,20 @@ __global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict
             res += Xi[a] * t;
         }
     }
-    if (lane < VSMPC_KIN_OUT) out[size_t(b) * VSMPC_KIN_OUT + lane] = res;
+    if (out != nullptr && lane < VSMPC_KIN_OUT) out[size_t(b) * VSMPC_KIN_OUT + lane] = res;
+    if (opts.records != nullptr && lane < VSMPC_KIN_OUT) {   // device-resident input records: LLIN | LANG | INERTIA
+        double* rec = opts.records + size_t(b) * opts.n_in;
+        rec[(lane < 24 ? VSMPC_IN_LLIN + lane : (lane < 48 ? VSMPC_IN_LANG + lane - 24 : VSMPC_IN_INERTIA + lane - 48))] = res;
+    }
+}
+
+hipError_t launch_kinematics_patch(const double* d_kin, int batch, double* d_records, int n_in, const KinOpts& opts,
+                                   hipStream_t stream) {
+    KinOpts o = opts;
+    o.records = d_records;
+    o.n_in = n_in;
+    hipLaunchKernelGGL(kinematics_kernel, dim3(batch), dim3(64), 0, stream, d_kin, batch, static_cast<double*>(nullptr), o);
+    return hipGetLastError();
 }
 
 hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, const KinOpts& opts, hipStream_t stream) {

@@ -31,8 +31,17 @@ hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, 
 struct KinOpts {
     int sel[VSMPC_N_JOINTS];   // robot joint index of every controlled joint (Lambda_ang columns)
     int constant_lambda;       // jointsLambdaOption "constant"
+    double* records = nullptr; // when set: LLIN | LANG | INERTIA are written into these device-resident input records
+    int n_in = 0;
 };
 hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, const KinOpts& opts, hipStream_t stream);
+
+// kinematics provider on a simplified tree (vsmpc_provider.hip)
+hipError_t launch_provider(const vsmpc_tree& tree, const double* d_state, int batch, double* d_kin, double* d_robot,
+                           double* d_records, int n_in, hipStream_t stream);
+// kinematics terms written straight into device-resident input records (LLIN, LANG, INERTIA)
+hipError_t launch_kinematics_patch(const double* d_kin, int batch, double* d_records, int n_in, const KinOpts& opts,
+                                   hipStream_t stream);
 
 // closed-loop rollout (vsmpc_rollout.hip)
 struct RolloutDev {

@@ -151,6 +151,24 @@ class BatchedVSMPC:
                    "vsmpc_kinematics_batch")
         return out[:, 0:24].reshape(-1, 3, 8), out[:, 24:48].reshape(-1, 3, 8), out[:, 48:57].reshape(-1, 3, 3)
 
+    def provider(self, tree: dict, states: np.ndarray, records: np.ndarray | None = None):
+        """vsmpc_provider_batch: the Robot quantities of the path on the simplified tree (robot_tree.py).  Returns
+        (kin[batch, KIN_SIZE], robot[batch, RO_SIZE]); `records`, when given, get the Robot-derived fields patched in
+        place (including Lambda_lin / Lambda_ang / I_G through the kinematics kernel, on the device)."""
+        from . import robot_tree as RT
+        states = np.ascontiguousarray(states, dtype=np.float64)
+        if states.ndim != 2 or states.shape[1] != RT.RS_SIZE:
+            raise ValueError(f"states must be [batch, {RT.RS_SIZE}]")
+        n = states.shape[0]
+        kin = np.empty((n, L.KIN_SIZE))
+        robot = np.empty((n, RT.RO_SIZE))
+        if records is not None:
+            assert records.flags["C_CONTIGUOUS"] and records.shape == (n, self.n_in)
+        ctree = RT.to_c(tree)
+        _lib.check(self.lib.vsmpc_provider_batch(self._h, ctypes.byref(ctree), _ptr(states), n, _ptr(kin), _ptr(robot),
+                                                 _ptr(records)), "vsmpc_provider_batch")
+        return kin, robot
+
     def set_kinematics_options(self, joint_selector=None, constant_lambda: bool = False):
         """vsmpc_set_kinematics_options: robot joint indices of the controlled joints (Lambda_ang columns; the
         reference selects them by name) and jointsLambdaOption 'constant'."""

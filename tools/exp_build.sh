@@ -9,7 +9,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   mkdir -p exp/$name
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wl,-rpath,/opt/rocm/lib $flags \
-      -o exp/$name/libvsmpc.so $PKG/csrc/vsmpc_kernels.hip $PKG/csrc/vsmpc_rollout.hip $PKG/csrc/vsmpc_capi.hip $PKG/csrc/vsmpc_jet.hip \
+      -o exp/$name/libvsmpc.so $PKG/csrc/vsmpc_kernels.hip $PKG/csrc/vsmpc_rollout.hip $PKG/csrc/vsmpc_capi.hip $PKG/csrc/vsmpc_jet.hip $PKG/csrc/vsmpc_provider.hip \
       > exp/$name/build.log 2>&1 && echo "built $name" || echo "FAILED $name" ) &
   pids+=($!)
 done

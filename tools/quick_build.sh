@@ -11,5 +11,5 @@ cp include/*.h exp/quick/src/include/
 echo "X($(echo $H | sed 's/,/, /g'))" > exp/quick/src/$PKG/csrc/vsmpc_horizons.def
 S=exp/quick/src/$PKG/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wl,-rpath,/opt/rocm/lib "$@" \
-    -o exp/quick/libvsmpc.so $S/vsmpc_kernels.hip $S/vsmpc_rollout.hip $S/vsmpc_capi.hip $S/vsmpc_jet.hip
+    -o exp/quick/libvsmpc.so $S/vsmpc_kernels.hip $S/vsmpc_rollout.hip $S/vsmpc_capi.hip $S/vsmpc_jet.hip $S/vsmpc_provider.hip
 echo "built exp/quick/libvsmpc.so for horizon $H"
