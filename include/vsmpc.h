@@ -308,6 +308,10 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
 int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream);
 /* Device -> host copies of the current plant state / of the records the NEXT tick will solve ([batch][n_in], parity
  * hook: after reset the records of tick 0, after run(k) those of tick k). */
+/* RPY / RPYDot tracks of the position trajectory (costsVSMPC.cpp:110-112,141-146: RPY reference = configure-time RPY +
+ * track, angular-momentum reference = I_G W RPYDot at the attitude of the push), [n_traj][3] each, at the position
+ * trajectory's rate; NULL = all zero (the shipped files).  Call before vsmpc_rollout_reset. */
+int vsmpc_rollout_set_attitude_tracks(vsmpc_rollout* r, const double* traj_rpy, const double* traj_rpy_dot);
 int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state);
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
 

@@ -55,11 +55,12 @@ int vsmpc_jet_plant_run_device(vsmpc_jet* j, float* d_T_nn, double* d_x_est, dou
                                int throttle_steps, int n, int steps, double dt, const double* Q, const double* R,
                                double* d_log, void* stream);
 
-/* Jet plant option of the closed-loop rollout (include/vsmpc.h, vsmpc_rollout_*): every 1 ms plant sub-step advances
- * the thrust of each jet with the LSTM model (thrust fed back, ironcub_mujoco_simulator.py:393-396) and updates the
- * jet's EKF with the NN's (T, Tdot) as measurement (:128-133); the plant's forces use the NN thrust, the MPC's records
- * (X0 thrusts and rates, linearisation point, Lambda terms) use the EKF estimates, as the harness does through
- * Robot::setJetThrusts.  State: VSMPC_PS_TNN / _EST / _EKFP of the plant state (set them in the state handed to
+/* Jet plant option of the closed-loop rollout (include/vsmpc.h, vsmpc_rollout_*): every 1 ms plant sub-step runs in the
+ * order of MujocoSim.step (ironcub_mujoco_simulator.py:128-133): the LSTM model advances the thrust of each jet (thrust
+ * fed back, :393-396), the jet's EKF takes the NN's (T, Tdot) as measurement, set_thrust(estimated_thrust) -- and then
+ * the body is stepped, so BOTH the plant's forces and the MPC's records (X0 thrusts and rates, linearisation point,
+ * Lambda terms, through Robot::setJetThrusts) use the EKF estimate of that sub-step; the NN's own output is kept only as
+ * its feedback state.  State: VSMPC_PS_TNN / _EST / _EKFP of the plant state (set them in the state handed to
  * vsmpc_rollout_reset).  Q, R: 2x2 row-major (ironcub_mujoco_simulator.py:54-56).  j == NULL switches back to the
  * polynomial jet plant.  The jet handle must outlive the rollout and live on the same device. */
 struct vsmpc_rollout;

@@ -68,6 +68,8 @@ struct vsmpc_rollout {
     double* d_tpos;
     double* d_tvel;
     double* d_talpha;
+    double* d_trpy;           // vsmpc_rollout_set_attitude_tracks (or nullptr)
+    double* d_trpyd;
     double* d_log;
     int log_ticks;
     double* d_tstate;         // per-instance tick state: reference window FIFO, RPY unwrap (see vsmpc_rollout.hip)
@@ -244,9 +246,15 @@ int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, dou
     if (h == nullptr || d_in == nullptr || d_status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(launch_solve(h->variant, h->form, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr,
-                         nullptr, static_cast<hipStream_t>(stream)));
+    // an enqueue-only entry must not change the caller's current device: set the handle's for the launch, put back the
+    // caller's afterwards (also on failure)
+    int caller_dev = -1;
+    HIP_TRY(hipGetDevice(&caller_dev));
+    if (caller_dev != h->device) HIP_TRY(hipSetDevice(h->device));
+    const hipError_t e = launch_solve(h->variant, h->form, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr,
+                                      nullptr, nullptr, static_cast<hipStream_t>(stream));
+    if (caller_dev != h->device) (void)hipSetDevice(caller_dev);
+    HIP_TRY(e);
     return VSMPC_OK;
 }
 
@@ -299,32 +307,40 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
     HIP_TRY(hipEventRecord(h->pipe_start, s));                 // work queued on the caller's stream comes first
     const int nstreams = std::min(PIPE_STREAMS, (batch + PIPE_CHUNK - 1) / PIPE_CHUNK);
     for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamWaitEvent(h->pipe[i], h->pipe_start, 0));
+    // A failure in the middle leaves earlier chunks queued: kernels that write straight into the caller's pinned buffers,
+    // copies into h->d_in.  Nothing returns before every pipe stream that was used has drained.
+    hipError_t err = hipSuccess;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; return err == hipSuccess; };
     int k = 0;
-    for (int first = 0; first < batch; first += PIPE_CHUNK, ++k) {
+    for (int first = 0; first < batch && err == hipSuccess; first += PIPE_CHUNK, ++k) {
         const int n = std::min(PIPE_CHUNK, batch - first);
         const size_t o = size_t(first), N = size_t(n);
         hipStream_t ps = h->pipe[k % nstreams];
-        HIP_TRY(hipMemcpyAsync(h->d_in + o * h->n_in, in + o * h->n_in, N * h->n_in * sizeof(double), hipMemcpyHostToDevice, ps));
+        if (!ok(hipMemcpyAsync(h->d_in + o * h->n_in, in + o * h->n_in, N * h->n_in * sizeof(double), hipMemcpyHostToDevice, ps))) break;
         if (direct) {
-            HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in + o * h->n_in, n, x ? zx + o * h->n_var : nullptr,
-                                 first_move ? zfm + o * VSMPC_FM_SIZE : nullptr, zst + o, iters ? zit + o : nullptr,
-                                 nullptr, nullptr, nullptr, ps));
+            ok(launch_solve(h->variant, h->form, h->dev, h->d_in + o * h->n_in, n, x ? zx + o * h->n_var : nullptr,
+                            first_move ? zfm + o * VSMPC_FM_SIZE : nullptr, zst + o, iters ? zit + o : nullptr,
+                            nullptr, nullptr, nullptr, ps));
             continue;
         }
-        HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
-                             h->d_fm + o * VSMPC_FM_SIZE, h->d_status + o, h->d_iters + o, nullptr, nullptr, nullptr, ps));
-        if (x) HIP_TRY(hipMemcpyAsync(x + o * h->n_var, h->d_x + o * h->n_var, N * h->n_var * sizeof(double), hipMemcpyDeviceToHost, ps));
+        if (!ok(launch_solve(h->variant, h->form, h->dev, h->d_in + o * h->n_in, n, h->d_x + o * h->n_var,
+                             h->d_fm + o * VSMPC_FM_SIZE, h->d_status + o, h->d_iters + o, nullptr, nullptr, nullptr, ps))) break;
+        if (x) ok(hipMemcpyAsync(x + o * h->n_var, h->d_x + o * h->n_var, N * h->n_var * sizeof(double), hipMemcpyDeviceToHost, ps));
         if (first_move)
-            HIP_TRY(hipMemcpyAsync(first_move + o * VSMPC_FM_SIZE, h->d_fm + o * VSMPC_FM_SIZE,
-                                   N * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, ps));
-        HIP_TRY(hipMemcpyAsync(status + o, h->d_status + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
-        if (iters) HIP_TRY(hipMemcpyAsync(iters + o, h->d_iters + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
+            ok(hipMemcpyAsync(first_move + o * VSMPC_FM_SIZE, h->d_fm + o * VSMPC_FM_SIZE,
+                              N * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, ps));
+        ok(hipMemcpyAsync(status + o, h->d_status + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
+        if (iters) ok(hipMemcpyAsync(iters + o, h->d_iters + o, N * sizeof(int), hipMemcpyDeviceToHost, ps));
     }
     for (int i = 0; i < nstreams; ++i) {
-        HIP_TRY(hipEventRecord(h->pipe_done[i], h->pipe[i]));
-        HIP_TRY(hipStreamWaitEvent(s, h->pipe_done[i], 0));   // the caller's stream continues after all of them
+        if (err == hipSuccess && ok(hipEventRecord(h->pipe_done[i], h->pipe[i])))
+            ok(hipStreamWaitEvent(s, h->pipe_done[i], 0));   // the caller's stream continues after all of them
     }
-    for (int i = 0; i < nstreams; ++i) HIP_TRY(hipStreamSynchronize(h->pipe[i]));
+    for (int i = 0; i < nstreams; ++i) {
+        const hipError_t e = hipStreamSynchronize(h->pipe[i]);
+        if (err == hipSuccess) err = e;
+    }
+    HIP_TRY(err);
     return VSMPC_OK;
 }
 
@@ -615,6 +631,8 @@ void vsmpc_rollout_destroy(vsmpc_rollout* r) {
     if (r->d_tpos) (void)hipFree(r->d_tpos);
     if (r->d_tvel) (void)hipFree(r->d_tvel);
     if (r->d_talpha) (void)hipFree(r->d_talpha);
+    if (r->d_trpy) (void)hipFree(r->d_trpy);
+    if (r->d_trpyd) (void)hipFree(r->d_trpyd);
     if (r->d_log) (void)hipFree(r->d_log);
     if (r->d_ctl) (void)hipFree(r->d_ctl);
     if (r->d_rec) (void)hipFree(r->d_rec);
@@ -638,6 +656,32 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
                           r->d_tstate, r->d_rec, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     r->valid = 1;
+    return VSMPC_OK;
+}
+
+int vsmpc_rollout_set_attitude_tracks(vsmpc_rollout* r, const double* traj_rpy, const double* traj_rpy_dot) {
+    if (r == nullptr) return VSMPC_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(r->h->device));
+    const size_t bytes = size_t(r->rd.n_traj) * 3 * sizeof(double);
+    auto set = [&](double*& dst, const double* src) -> hipError_t {
+        if (src == nullptr) {
+            if (dst) (void)hipFree(dst);
+            dst = nullptr;
+            return hipSuccess;
+        }
+        if (dst == nullptr) {
+            hipError_t e = hipMalloc(&dst, bytes);
+            if (e != hipSuccess) return e;
+        }
+        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(set(r->d_trpy, traj_rpy));
+    HIP_TRY(set(r->d_trpyd, traj_rpy_dot));
+    r->rd.traj_rpy = r->d_trpy;
+    r->rd.traj_rpyd = r->d_trpyd;
+    if (r->gexec) { (void)hipGraphExecDestroy(r->gexec); r->gexec = nullptr; }   // the captured ticks hold the old arguments
+    r->graph_state = 0;
+    r->valid = 0;                                                                // vsmpc_rollout_reset before the next run
     return VSMPC_OK;
 }
 

@@ -49,6 +49,8 @@ struct RolloutDev {
     int n_ts;         // doubles of per-instance tick state (reference window, RPY unwrap: see vsmpc_rollout.hip)
     int alpha_up;     // up-sampling factor of the alpha-gravity track (TrajectoryManager.cpp:23-39)
     double period_mpc, alpha_dt;
+    const double* traj_rpy;      // device, [n_traj][3] or nullptr: RPY / RPYDot tracks of the position trajectory
+    const double* traj_rpyd;     //   (vsmpc_rollout_set_attitude_tracks; the shipped ones are all zero)
     // jet plant option (vsmpc_rollout_set_jet_plant): LSTM thrust dynamics + EKF estimates instead of the polynomial model
     int jet_nn, jet_hidden;
     const float* jet_w;          // device: wih col 0 [4H] | wih col 1 [4H] | b_ih [4H] | b_hh [4H] | fc_w [H] | fc_b

@@ -97,7 +97,8 @@ VS_DEV double wrap_pi(double a) {  // what Rotation::asRPY() returns for an angl
 // original sample is dropped), cursor advanced once per dynamics evaluation and clamped at the last up-sampled sample
 // (:142-153); configure consumed sample 0, so tick k reads sample k + 1.
 VS_DEV double alpha_of_tick(const double* __restrict__ tr, int n, int up, int tk) {
-    const int last = up * (n - 1) - 1;
+    // (a track already at the requested rate is NOT resampled and keeps all n samples, TrajectoryManager.cpp:121-126)
+    const int last = up == 1 ? n - 1 : up * (n - 1) - 1;
     int idx = tk + 1;
     idx = idx < last ? idx : last;
     idx = idx > 0 ? idx : 0;
@@ -148,8 +149,23 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
             const int c = i - 3;
             return R[c] * (m * traj_vel[3 * idx]) + R[3 + c] * (m * traj_vel[3 * idx + 1]) + R[6 + c] * (m * traj_vel[3 * idx + 2]);
         }
-        if (i < 9) return p[VSMPC_PP_RPYINIT + i - 6];                      // m_initialRPY + RPY trajectory (all zero, A.6)
-        return 0.0;                                                         // I_G W rpy_dot_ref, RPYDot trajectory all zero
+        if (i < 9)                                                          // m_initialRPY + RPY trajectory
+            return p[VSMPC_PP_RPYINIT + i - 6] + (rd.traj_rpy != nullptr ? rd.traj_rpy[3 * idx + i - 6] : 0.0);
+        if (rd.traj_rpyd == nullptr) return 0.0;                            // the shipped RPYDot track is all zero (A.6)
+        // m_inertia * m_W * RPYDot with the CURRENT attitude (costsVSMPC.cpp:111-112,143-146,266-286); the locked inertia
+        // of this plant is R I_B R^T
+        const double r0 = s[VSMPC_PS_RPY], p0 = s[VSMPC_PS_RPY + 1];
+        const double d0 = rd.traj_rpyd[3 * idx], d1 = rd.traj_rpyd[3 * idx + 1], d2 = rd.traj_rpyd[3 * idx + 2];
+        const double wd[3] = {d0 - sin(p0) * d2, cos(r0) * d1 + cos(p0) * sin(r0) * d2, -sin(r0) * d1 + cos(r0) * cos(p0) * d2};
+        double acc = 0.0;
+        const int row = i - 9;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                double rw = 0.0;
+                for (int j = 0; j < 3; ++j) rw += R[3 * j + c] * wd[j];     // (R^T wd)[c]
+                acc += R[3 * row + a] * p[VSMPC_PP_INERTIA_B + 3 * a + c] * rw;
+            }
+        return acc;
     };
     if (first) {
         // shifts made before update() number tk: the one of configure + one per earlier tick with k % ratio == ratio - 1;
@@ -326,6 +342,38 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
             const double t = (double(tk) + double(ss) / double(substeps)) * rd.period_mpc;
             const double alpha = alpha_s[ss];
             const bool dist = t >= p[VSMPC_PP_DIST_T0] && t < p[VSMPC_PP_DIST_T1];
+            if (rd.jet_nn) {
+                // jet plant option, one plant step in the order of MujocoSim.step (ironcub_mujoco_simulator.py:128-133,
+                // 393-396): the NN advances every jet's thrust from its own previous output (hidden units over the lanes),
+                // the jet's EKF takes the NN's (T, Tdot) as measurement, set_thrust(estimated_thrust) -- and only then the
+                // body is stepped: the force of THIS sub-step is the EKF estimate of this sub-step.
+                const JetNorm nm{rd.jet_norm[0], rd.jet_norm[1], rd.jet_norm[2], rd.jet_norm[3]};
+                float Tn_mine = 0.0f, Tdn_mine = 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    float x0, x1;
+                    jet_normalize(nm, float(s[VSMPC_PS_TNN + j]), float(s[VSMPC_PS_U + j]), x0, x1);
+                    const float out = lstm_step_from_zero_wave(jw, rd.jet_hidden, x0, x1, lane);
+                    const float Tn = (x0 + out * float(h)) * float(nm.thrust_std) + float(nm.thrust_mean);
+                    const float Tdn = out * float(nm.thrust_std);
+                    if (lane == j) { Tn_mine = Tn; Tdn_mine = Tdn; }
+                }
+                __syncthreads();                              // every lane has read s[TNN] before lanes 0..3 update it
+                if (lane < 4) {
+                    Ekf2 cv;
+                    for (int k = 0; k < 4; ++k) { cv.q[k] = rd.ekf_q[k]; cv.r[k] = rd.ekf_r[k]; }
+                    double T = s[VSMPC_PS_EST + 2 * lane], Td = s[VSMPC_PS_EST + 2 * lane + 1];
+                    double Pm[4] = {s[VSMPC_PS_EKFP + 4 * lane], s[VSMPC_PS_EKFP + 4 * lane + 1],
+                                    s[VSMPC_PS_EKFP + 4 * lane + 2], s[VSMPC_PS_EKFP + 4 * lane + 3]};
+                    ekf_update_dev(T, Td, Pm, s[VSMPC_PS_U + lane], double(Tn_mine), double(Tdn_mine), h, cv);
+                    s[VSMPC_PS_EST + 2 * lane] = T;
+                    s[VSMPC_PS_EST + 2 * lane + 1] = Td;
+                    for (int k = 0; k < 4; ++k) s[VSMPC_PS_EKFP + 4 * lane + k] = Pm[k];
+                    s[VSMPC_PS_TNN + lane] = double(Tn_mine);   // the NN's own feedback state
+                    x[12 + lane] = T;                           // set_thrust(self._estimated_thrust)
+                    x[16 + lane] = Td;
+                }
+                __syncthreads();
+            }
             if (lane < 3) {
                 double sn, cs;
                 sincos(x[6 + lane], &sn, &cs);
@@ -375,37 +423,6 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
             __syncthreads();                                  // every lane has read x before anyone updates it
             if (lane < 20) x[lane] += h * d;
             __syncthreads();
-            if (rd.jet_nn) {
-                // jet plant option, one plant step (ironcub_mujoco_simulator.py:128-133,393-396): the NN advances every
-                // jet's thrust from its own previous output (hidden units over the lanes), then the jet's EKF takes the
-                // NN's (T, Tdot) as measurement.  The forces of the NEXT sub-step see the new NN thrust.
-                const JetNorm nm{rd.jet_norm[0], rd.jet_norm[1], rd.jet_norm[2], rd.jet_norm[3]};
-                float Tn_mine = 0.0f, Tdn_mine = 0.0f;
-                for (int j = 0; j < 4; ++j) {
-                    float x0, x1;
-                    jet_normalize(nm, float(s[VSMPC_PS_TNN + j]), float(s[VSMPC_PS_U + j]), x0, x1);
-                    const float out = lstm_step_from_zero_wave(jw, rd.jet_hidden, x0, x1, lane);
-                    const float Tn = (x0 + out * float(h)) * float(nm.thrust_std) + float(nm.thrust_mean);
-                    const float Tdn = out * float(nm.thrust_std);
-                    if (lane == j) { Tn_mine = Tn; Tdn_mine = Tdn; }
-                }
-                __syncthreads();                              // every lane has read s[TNN] before lanes 0..3 update it
-                if (lane < 4) {
-                    Ekf2 cv;
-                    for (int k = 0; k < 4; ++k) { cv.q[k] = rd.ekf_q[k]; cv.r[k] = rd.ekf_r[k]; }
-                    double T = s[VSMPC_PS_EST + 2 * lane], Td = s[VSMPC_PS_EST + 2 * lane + 1];
-                    double Pm[4] = {s[VSMPC_PS_EKFP + 4 * lane], s[VSMPC_PS_EKFP + 4 * lane + 1],
-                                    s[VSMPC_PS_EKFP + 4 * lane + 2], s[VSMPC_PS_EKFP + 4 * lane + 3]};
-                    ekf_update_dev(T, Td, Pm, s[VSMPC_PS_U + lane], double(Tn_mine), double(Tdn_mine), h, cv);
-                    s[VSMPC_PS_EST + 2 * lane] = T;
-                    s[VSMPC_PS_EST + 2 * lane + 1] = Td;
-                    for (int k = 0; k < 4; ++k) s[VSMPC_PS_EKFP + 4 * lane + k] = Pm[k];
-                    s[VSMPC_PS_TNN + lane] = double(Tn_mine);
-                    x[12 + lane] = double(Tn_mine);
-                    x[16 + lane] = double(Tdn_mine);
-                }
-                __syncthreads();
-            }
         }
         if (lane < 20) s[lane] = x[lane];
         if (lane == 0) tick[b] = tick_before + 1;
@@ -418,14 +435,15 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
     if (log != nullptr && lane < VSMPC_ROLLOUT_LOG) {
         const int row = tick_before - tick_base;   // ticks since the start of this run
         double v;
-        if (row < 0 || row >= log_rows) return;   // a run that failed half-way leaves the counters ahead: never write outside the log
         if (lane < 3) v = s[lane];
         else if (lane < 6) v = s[6 + lane - 3];
         else if (lane < 10) v = s[12 + lane - 6];
         else if (lane < 14) v = s[VSMPC_PS_U + lane - 10];
         else if (lane == 14) v = double(st);
         else v = iters ? double(iters[b]) : 0.0;
-        log[(size_t(row) * batch + b) * VSMPC_ROLLOUT_LOG + lane] = v;
+        // a run that failed half-way leaves the counters ahead: never write outside the log (and never leave the
+        // workgroup here: the record of the next tick is assembled below, with barriers)
+        if (row >= 0 && row < log_rows) log[(size_t(row) * batch + b) * VSMPC_ROLLOUT_LOG + lane] = v;
     }
     if (rec_next != nullptr) {
         assemble_record(rd, s, p, tick_before + 1 + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, false);

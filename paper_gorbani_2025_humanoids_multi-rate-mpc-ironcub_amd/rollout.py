@@ -157,6 +157,7 @@ class ClosedLoopRollout:
         alpha = np.ascontiguousarray(traj_alpha, dtype=np.float64)
         if pos.shape != vel.shape or pos.ndim != 2 or pos.shape[1] != 3:
             raise ValueError("traj_pos / traj_vel must be [n, 3]")
+        self.n_traj = pos.shape[0]
         self._r = ctypes.c_void_p()
         _lib.check(self.lib.vsmpc_rollout_create(self.mpc._h, batch, _ptr(pos), _ptr(vel), pos.shape[0], _ptr(alpha),
                                                  alpha.shape[0], float(alpha_dt), ctypes.byref(self._r)),
@@ -181,6 +182,16 @@ class ClosedLoopRollout:
         if state.shape != (self.batch, L.PLANT_STATE) or params.shape != (self.batch, L.PLANT_PARAMS):
             raise ValueError("state / params shape does not match the rollout batch")
         _lib.check(self.lib.vsmpc_rollout_reset(self._r, _ptr(state), _ptr(params)), "vsmpc_rollout_reset")
+
+    def set_attitude_tracks(self, traj_rpy=None, traj_rpy_dot=None):
+        """RPY / RPYDot tracks of the position trajectory (vsmpc_rollout_set_attitude_tracks; costsVSMPC.cpp:110-112,
+        141-146), [n_traj, 3] each or None (all zero, the shipped files).  Call reset() afterwards."""
+        a = None if traj_rpy is None else np.ascontiguousarray(traj_rpy, dtype=np.float64)
+        b = None if traj_rpy_dot is None else np.ascontiguousarray(traj_rpy_dot, dtype=np.float64)
+        for t in (a, b):
+            if t is not None and t.shape != (self.n_traj, 3):
+                raise ValueError(f"attitude tracks must be [{self.n_traj}, 3]")
+        _lib.check(self.lib.vsmpc_rollout_set_attitude_tracks(self._r, _ptr(a), _ptr(b)), "vsmpc_rollout_set_attitude_tracks")
 
     def set_jet_plant(self, jet_model=None, Q=None, R=None):
         """Jet plant option (vsmpc_rollout_set_jet_plant): `jet_model` = a jet_plant.JetModelTotal (the LSTM thrust model;

@@ -91,9 +91,9 @@ def measured(s, jet=None):
 
 def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5, jet=None):
     """Returns the plant state after one tick (first move applied only if status == 1).  `jet` = (JetLSTM, Q, R) of
-    oracle/jet_ref.py selects the jet plant option: per sub-step the mechanical state advances with the current NN thrust,
-    then every jet's thrust is advanced by the LSTM (thrust fed back) and its EKF is updated with the NN's (T, Tdot)
-    (ironcub_mujoco_simulator.py:128-133,393-396)."""
+    oracle/jet_ref.py selects the jet plant option, in the order of MujocoSim.step (ironcub_mujoco_simulator.py:128-133,
+    393-396): per sub-step every jet's thrust is advanced by the LSTM (thrust fed back), its EKF is updated with the NN's
+    (T, Tdot), set_thrust(estimated_thrust) -- and then the mechanical state advances with the EKF ESTIMATE as the force."""
     s = s.copy()
     if status == 1:
         s[L.PS_Q:L.PS_Q + 8] += fm[L.FM_DQ:L.FM_DQ + 8]
@@ -112,6 +112,19 @@ def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5, jet=N
         t = (tk + ss / substeps) * cfg.period_mpc
         alpha = interp_clamped(traj_alpha, t / alpha_dt)
         dist = p[L.PP_DIST_T0] <= t < p[L.PP_DIST_T1]
+        if jet is not None:
+            import jet_ref
+            lstm, Q, Rm = jet
+            u = s[L.PS_U:L.PS_U + 4]
+            Tn, Tdn, _, _ = lstm.get_state(s[L.PS_TNN:L.PS_TNN + 4].astype(np.float32), u.astype(np.float32), np.float32(h))
+            for i in range(4):
+                est, P = jet_ref.ekf_update(s[L.PS_EST + 2 * i:L.PS_EST + 2 * i + 2], s[L.PS_EKFP + 4 * i:L.PS_EKFP + 4 * i + 4].reshape(2, 2),
+                                            float(u[i]), [float(Tn[i]), float(Tdn[i])], h, Q, Rm)
+                s[L.PS_EST + 2 * i:L.PS_EST + 2 * i + 2] = est
+                s[L.PS_EKFP + 4 * i:L.PS_EKFP + 4 * i + 4] = P.reshape(-1)
+            s[L.PS_TNN:L.PS_TNN + 4] = Tn                       # the NN's own feedback state
+            x[12:16] = s[L.PS_EST:L.PS_EST + 8:2]               # set_thrust(self._estimated_thrust)
+            x[16:20] = s[L.PS_EST + 1:L.PS_EST + 8:2]
         R = rot(x[6:9])
         om = np.linalg.solve(IB, x[9:12])
         d = np.zeros(20)
@@ -135,18 +148,5 @@ def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5, jet=N
         if jet is not None:
             d[12:20] = 0.0
         x = x + h * d
-        if jet is not None:
-            import jet_ref
-            lstm, Q, Rm = jet
-            u = s[L.PS_U:L.PS_U + 4]
-            Tn, Tdn, _, _ = lstm.get_state(s[L.PS_TNN:L.PS_TNN + 4].astype(np.float32), u.astype(np.float32), np.float32(h))
-            for i in range(4):
-                est, P = jet_ref.ekf_update(s[L.PS_EST + 2 * i:L.PS_EST + 2 * i + 2], s[L.PS_EKFP + 4 * i:L.PS_EKFP + 4 * i + 4].reshape(2, 2),
-                                            float(u[i]), [float(Tn[i]), float(Tdn[i])], h, Q, Rm)
-                s[L.PS_EST + 2 * i:L.PS_EST + 2 * i + 2] = est
-                s[L.PS_EKFP + 4 * i:L.PS_EKFP + 4 * i + 4] = P.reshape(-1)
-            s[L.PS_TNN:L.PS_TNN + 4] = Tn
-            x[12:16] = Tn
-            x[16:20] = Tdn
     s[0:20] = x
     return s

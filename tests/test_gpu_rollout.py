@@ -133,7 +133,7 @@ def test_jet_plant_option_closed_loop_properties(ro, layout):
     tnn = final[:, layout.PS_TNN:layout.PS_TNN + 4]
     assert np.abs(est - tnn).max() < 2.0                       # N: the estimate follows the plant thrust
     assert (tnn > 50).all() and (tnn < 260).all()
-    np.testing.assert_array_equal(final[:, layout.PS_T:layout.PS_T + 4], tnn)
+    np.testing.assert_array_equal(final[:, layout.PS_T:layout.PS_T + 4], est)     # the applied thrust IS the estimate (set_thrust)
     z_err = np.abs(log[-50:, :, 2] - pa[None, :, layout.PP_PINIT + 2])
     assert np.median(z_err) < 0.1 and z_err.max() < 0.6
     assert np.isfinite(final).all()
@@ -181,6 +181,52 @@ def test_tick_state_machine_matches_reference_model(ro, layout):
                 np.testing.assert_allclose(s_host[b, layout.PS_Q:layout.PS_Q + 8], models[b].m_jointsPositionReference, rtol=0, atol=1e-15)
         assert crossed.all()                                   # every loop went through +-pi with its turn counter
         assert all(abs(m.init_state.m_nTurns[2]) == 1 for m in models)
+    finally:
+        r.close()
+
+
+def test_attitude_tracks_and_native_rate_alpha(ro, layout):
+    """Non-zero RPY / RPYDot tracks (vsmpc_rollout_set_attitude_tracks): the RPY reference is the configure-time RPY + the
+    track and the angular-momentum reference m_inertia * m_W * RPYDot at the attitude of the push
+    (costsVSMPC.cpp:110-112,141-146,266-286); and an alpha-gravity track already at 1 / periodMPC, which the reference
+    does NOT resample and follows to its last sample (TrajectoryManager.cpp:121-126).  Records against the reference-derived
+    model over 45 ticks (two pushes)."""
+    import os
+    import tick_model as tm
+    from conftest import ROOT
+    cfg = layout.paper_config()
+    pos, vel, alpha, adt = ro.load_reference_trajectories(os.path.join(ROOT, "tests", "golden", "reference_trajectories.npz"))
+    n = len(pos)
+    t = np.arange(n)[:, None] / 10.0
+    rpy = 0.05 * np.sin(0.3 * t) * np.array([[1.0, -0.5, 0.2]])
+    rpyd = 0.015 * np.cos(0.3 * t) * np.array([[1.0, -0.5, 0.2]])
+    alpha200 = np.linspace(0.3, 1.0, 31)                       # 31 samples at 200 Hz: exhausted after 30 ticks
+    B = 3
+    st, pa = ro.make_plant(cfg, B, workload="hover", seed0=7)
+    for b in range(B):
+        pa[b, layout.PP_TICK0] = 0.0
+        st[b, layout.PS_HANG] = 0.6
+        pa[b, layout.PP_PINIT:layout.PP_PINIT + 3] = st[b, layout.PS_P:layout.PS_P + 3]
+        pa[b, layout.PP_RPYINIT:layout.PP_RPYINIT + 3] = tm.as_rpy(st[b, layout.PS_RPY:layout.PS_RPY + 3])
+    r = ro.ClosedLoopRollout(cfg, B, pos, vel, alpha200, cfg.period_mpc, device=0)
+    try:
+        r.set_attitude_tracks(rpy, rpyd)
+        r.reset(st, pa)
+        models = [tm.ReferenceTickModel(cfg, st[b], pa[b], pos, vel, alpha200, fps_alpha=200, traj_rpy=rpy, traj_rpy_dot=rpyd)
+                  for b in range(B)]
+        s_host = st.copy()
+        for tick in range(45):
+            recs = r.next_records()
+            for b in range(B):
+                rec_m = tm.record_from_tick(cfg, models[b].update(s_host[b]), rm.kin_record(cfg, s_host[b], pa[b]))
+                assert relerr(recs[b], rec_m) < 1e-12, (tick, b, int(np.abs(recs[b] - rec_m).argmax()))
+            x, fm, status, iters = r.mpc.solve(recs)
+            for b in range(B):
+                models[b].consume(fm[b], status[b])
+            r.run(1, log=False)
+            s_host = r.state()
+        assert np.abs(recs[:, layout.IN_XREF + 9:layout.IN_XREF + 12]).max() > 1e-3      # a non-zero h_ang reference got in
+        assert (recs[:, layout.IN_ALPHA] == alpha200[-1]).all()                          # held at the LAST sample of the track
     finally:
         r.close()
 

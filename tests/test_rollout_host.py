@@ -147,4 +147,6 @@ def test_model_jet_stage_is_the_oracle_plant_run():
         np.testing.assert_array_equal(after[L.PS_TNN:L.PS_TNN + 4], Tn.astype(np.float64))
         np.testing.assert_allclose(after[L.PS_EST:L.PS_EST + 8], est.reshape(-1), rtol=0, atol=1e-12)
         np.testing.assert_allclose(after[L.PS_EKFP:L.PS_EKFP + 16], P.reshape(-1), rtol=0, atol=1e-14)
-        np.testing.assert_array_equal(after[L.PS_T:L.PS_T + 4], after[L.PS_TNN:L.PS_TNN + 4])      # the forces see the NN thrust
+        # set_thrust(self._estimated_thrust): the force the body sees is the EKF estimate (ironcub_mujoco_simulator.py:131-133)
+        np.testing.assert_array_equal(after[L.PS_T:L.PS_T + 4], after[L.PS_EST:L.PS_EST + 8:2])
+        np.testing.assert_array_equal(after[L.PS_TD:L.PS_TD + 4], after[L.PS_EST + 1:L.PS_EST + 8:2])

@@ -106,6 +106,12 @@ class Robot:
     def getJetThrusts(self):
         return self.s[L.PS_T:L.PS_T + 4]
 
+    def getLockedInertia(self):
+        """(X^T M_b X).block(3, 3, 3, 3) of costsVSMPC.cpp:266-286: the world-oriented locked inertia, R I_B R^T for the
+        synthetic plant"""
+        R = self.getRotation()
+        return R @ self.p[L.PP_INERTIA_B:L.PP_INERTIA_B + 9].reshape(3, 3) @ R.T
+
 
 class QPInput:
     """Fields of the QPInput bus the path reads / writes (utils/include/QPInput.h:12-124)."""
@@ -132,8 +138,10 @@ class ReferenceTrackingCost:
         p = self.m_initialCoMPos + self.m_trajManager.getCurrentValue("positionCoM")
         hl = robot.getRotation().T @ (robot.getTotalMass() * self.m_trajManager.getCurrentValue("velocityCoM"))
         rpy = self.m_initialRPY + self.m_trajManager.getCurrentValue("RPY")
-        ha = np.zeros(3)   # m_inertia * m_W * RPYDot with the all-zero RPYDot track of the shipped trajectory
-        assert not np.any(self.m_trajManager.getCurrentValue("RPYDot"))
+        r0, p0 = robot.asRPY()[0], robot.asRPY()[1]                                                  # updateInertiaMatrix, :266-286
+        W = np.array([[1.0, 0.0, -math.sin(p0)], [0.0, math.cos(r0), math.cos(p0) * math.sin(r0)],
+                      [0.0, -math.sin(r0), math.cos(r0) * math.cos(p0)]])
+        ha = robot.getLockedInertia() @ W @ self.m_trajManager.getCurrentValue("RPYDot")              # m_inertia * m_W * RPYDot
         return p, hl, rpy, ha
 
     def configureDynVectorsSize(self, robot):                                                        # :74-119
@@ -235,13 +243,15 @@ class ReferenceTickModel:
     """VariableSamplingMPC + the harness's feedback into QPInput, for one instance of the synthetic plant."""
 
     def __init__(self, cfg, s0, p, traj_pos, traj_vel, traj_alpha, fps_traj=10, fps_alpha=10, ticks_before=0,
-                 configured_elsewhere=False):
+                 configured_elsewhere=False, traj_rpy=None, traj_rpy_dot=None):
         """`ticks_before` > 0 with `configured_elsewhere`: the loop was configured earlier, at CoM PP_PINIT / attitude
         PP_RPYINIT, and has run `ticks_before` ticks with the CURRENT attitude and state (the definition the device uses
         for loops that start mid-trajectory); reproduced by running the state machine that many times on `s0`."""
         self.cfg, self.p = cfg, np.asarray(p, float)
         n = len(traj_pos)
-        tracks = {"positionCoM": traj_pos, "velocityCoM": traj_vel, "RPY": np.zeros((n, 3)), "RPYDot": np.zeros((n, 3))}
+        tracks = {"positionCoM": traj_pos, "velocityCoM": traj_vel,
+                  "RPY": np.zeros((n, 3)) if traj_rpy is None else traj_rpy,
+                  "RPYDot": np.zeros((n, 3)) if traj_rpy_dot is None else traj_rpy_dot}
         self.cost = ReferenceTrackingCost(cfg, tracks, fps_traj)
         self.throttle = ThrottleConstraint(cfg)
         self.linmom = LinearMomentumDynamicVS(cfg, traj_alpha, fps_alpha)
