@@ -6,9 +6,10 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One *step* = one pass of the hot path (linearise -> condense -> factor -> box QP -> simulate) over one
-batch of synthetic instances that is already resident in HBM.  At N=1 the batch is
-BASELINE.json configs[1] (batch=256 hover initial states, paper horizon/rates); with N ranks every
-rank solves its own 256-instance slice (weak scaling, per-rank seeds, no data-path collective).
+batch of synthetic instances that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]
+(batch=256 hover initial states, paper horizon/rates).  With N > 1 ranks the line carries BASELINE.json configs[3] --
+the Monte-Carlo batch sharded over the GPUs, 4096 instances with 4x wider scatter per rank, per-rank seeds, no
+data-path collective (weak scaling) -- and the 256-per-GPU figure moves into `extra_configs`.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -30,6 +31,17 @@ PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
 F_ALG = {"paper": 3.086e6, "horizon2x": 6.17e6}
 BYTES_ALG = {"paper": 7064, "horizon2x": 12488}
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector/matrix peak (AMD spec; not listed in MI355X_MICROARCH.md)
+
+
+def cpu_structured(cfg_name: str, inputs: np.ndarray, budget_s: float = 8.0):
+    """Second CPU line: the kernel's OWN algorithm (condense -> Cholesky -> box QP) as scalar C on the
+    host cores, so that the algorithmic gain over the reference's OSQP route and the hardware gain can be told apart."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c
+        return oracle_c.time_structured(cfg_name, inputs, budget_s)
+    except Exception as exc:  # pragma: no cover
+        return {"value": None, "unit": "solves/s", "note": f"unavailable ({type(exc).__name__}: {exc})"}
 
 
 def cpu_baseline(cfg_name: str, inputs: np.ndarray, budget_s: float = 15.0):
@@ -62,6 +74,22 @@ def kernel_form(mpc, batch, dev):
             + f"; 4 wavefronts, {wgs}")
 
 
+def counters_of(config: str, workload: str, batch: int):
+    """Counter-derived figures of this configuration from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json,
+    profiles/mfma_counters.json; tools/prof_r03.sh).  They describe the kernel version named in `counters_from`, measured
+    on the builder's lease -- NOT this run."""
+    key = f"{config}:{workload}:{batch}"
+    out = {"traffic": None, "mfma_busy_frac": None, "counters_from": None}
+    for fname, field, dst in (("hbm_traffic.json", "bytes_per_launch", "traffic"), ("mfma_counters.json", "mfma_busy_frac", "mfma_busy_frac")):
+        path = os.path.join(ROOT, "profiles", fname)
+        if os.path.exists(path):
+            rec = json.load(open(path)).get(key)
+            if rec:
+                out[dst] = rec.get(field)
+                out["counters_from"] = rec.get("tag", out["counters_from"])
+    return out
+
+
 def parity_sample(cfg_name: str, inputs: np.ndarray, x: np.ndarray, k: int = 8) -> float:
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vsmpc_ref as ref
@@ -85,7 +113,7 @@ EXTRA_CONFIGS = (
 )
 
 
-def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, world, distributed):
+def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, world, distributed, red_dev=None):
     """One extra configuration: every rank solves its own `batch`-instance slice; max-over-ranks timing."""
     import torch
     import torch.distributed as dist
@@ -119,10 +147,14 @@ def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, wor
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([int((d_st == 1).sum().item()), int(d_it.sum().item())], dtype=torch.int64, device=dev)
+    red_dev = dev if red_dev is None else red_dev
+    own = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)   # this rank's own wall-clock for the K steps
+    red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
+    lo = own.clone()
+    cnt = torch.tensor([int((d_st == 1).sum().item()), int(d_it.sum().item()), 1], dtype=torch.int64, device=red_dev)
     if distributed:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     rec = None
     if rank == 0:
@@ -137,7 +169,11 @@ def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, wor
                "roofline_frac": tf / FP64_PEAK_TFLOPS, "achieved_tflops": tf,
                "solved": int(cnt[0].item()), "instances_per_step": B * world,
                "mean_active_set_iterations": float(cnt[1].item()) / (B * world),
+               # ranks that took part in the all-reduce, and the spread of the per-rank rates (slowest .. fastest rank)
+               "rccl_ranks": int(cnt[2].item()) if distributed else 1,
+               "per_rank_solves_per_s": {"min": B * spec["steps"] / elapsed, "max": B * spec["steps"] / float(lo[0].item())},
                "parity_max_rel_err_vs_oracle": parity_sample(spec["config"], inputs, x_host, k=6)}
+        rec.update(counters_of(spec["config"], spec["workload"], B))
     mpc.close()
     return rec
 
@@ -165,15 +201,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MPC path has no CPU fallback")
+    # VSMPC_BENCH_BACKEND=gloo rehearses the N > 1 code path (slicing, barriers, reductions, the JSON line) on a box with
+    # fewer GPUs than ranks: ranks share the devices and the reductions run on host tensors.  Not a measurement.
+    backend = os.environ.get("VSMPC_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearsal else dev
     # under torch.distributed.run (RANK set) the RCCL group is created even for one rank, so that the same code path
     # (init, barrier, all_reduce) runs at every N
     distributed = world > 1 or "RANK" in os.environ
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
@@ -187,8 +233,20 @@ def main():
 
     cfg = pkg.paper_config() if args.config == "paper" else pkg.horizon2x_config()
     B = args.batch
-    first, count = sharding.shard_range(B * world, rank, world)   # contiguous slice, no exchange
-    inputs = synth.make_batch(cfg, count, workload=args.workload, first_index=first)
+    default_line = args.config == "paper" and args.workload == "hover" and B == 256
+    # N > 1 with the default flags: BASELINE.json configs[3] goes on the line -- 4096 Monte-Carlo instances (4x sigma) per
+    # rank, rank r owning the global instances [r * 4096, (r + 1) * 4096) with its own seeds (sharding.rank_inputs)
+    multi = world > 1 and default_line
+    workload = args.workload
+    if multi:
+        B, workload = 4096, "montecarlo"
+        inputs = sharding.rank_inputs(cfg, synth, B * world, rank, world, workload=workload)
+        count = B
+        if args.steps == 200:
+            args.steps, args.warmup = 60, 6           # 60 x 0.43 ms: the same wall-clock order as 200 x 46 us
+    else:
+        first, count = sharding.shard_range(B * world, rank, world)   # contiguous slice, no exchange
+        inputs = synth.make_batch(cfg, count, workload=workload, first_index=first)
     mpc = solver.BatchedVSMPC(cfg, device=local_rank, max_batch=count)
 
     d_in = torch.from_numpy(inputs).to(dev)
@@ -219,31 +277,31 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    solved = torch.tensor([int((d_st == 1).sum().item())], dtype=torch.int64, device=dev)
-    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tmin = t.clone()
+    solved = torch.tensor([int((d_st == 1).sum().item()), 1], dtype=torch.int64, device=red_dev)   # [solved, 1 per rank]
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(solved, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    total_solved = int(solved.item())
+    fastest = float(tmin.item())
+    total_solved = int(solved[0].item())
+    rccl_ranks = int(solved[1].item()) if distributed else 1      # every rank added 1: proves the collective saw N ranks
     kernel_ms = float(kms.item())
 
     if rank == 0:
         total = B * world
         value = total * args.steps / elapsed
         achieved_tflops = F_ALG[args.config] * count / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            rec = json.load(open(tpath)).get(f"{args.config}:{args.workload}:{B}")
-            traffic = rec["bytes_per_launch"] if rec else None
-        mfma_busy = None
-        mpath = os.path.join(ROOT, "profiles", "mfma_counters.json")
-        if os.path.exists(mpath):   # SQ_VALU_MFMA_BUSY_CYCLES share, separate rocprofv3 --pmc pass (tools/prof_mfma.sh)
-            rec = json.load(open(mpath)).get(f"{args.config}:{args.workload}:{B}")
-            mfma_busy = rec["mfma_busy_frac"] if rec else None
+        ctr = counters_of(args.config, workload, B)
+        horizon = ("paper horizon/rates (nIter=17,nIterSmall=7,controlHorizon=12)" if args.config == "paper"
+                   else "2x horizon (nIter=34,nIterSmall=14,controlHorizon=24)")
+        what = (f"BASELINE configs[3]: {total} Monte-Carlo initial states (4x sigma) sharded over {world} GPUs, {B} per GPU, "
+                f"per-rank seeds, {horizon}" if multi else
+                f"batch={B} {workload} initial states per GPU, {horizon}")
         out = {
             # BASELINE.json's metric; `value` is the solves/s part, the p50 latency part is `latency_single_solve_us`
             "metric": "MPC solves/sec (whole node) + p50 single-solve latency, iRonCub paper horizon"
@@ -251,12 +309,14 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch={B} {args.workload} initial states per GPU, "
-                                   f"{'paper horizon/rates (nIter=17,nIterSmall=7,controlHorizon=12)' if args.config == 'paper' else '2x horizon (nIter=34,nIterSmall=14,controlHorizon=24)'}",
+            "config": {"workload": what,
                        "instances_total": total, "qp": f"{cfg.n_var} vars / {cfg.n_con} rows",
                        "parallelism": f"batch split over {world} GPU(s), no data-path collective"},
+            "rccl_ranks": rccl_ranks, "collective_backend": ("rccl" if not rehearsal else backend + " (rehearsal, not a measurement)") if distributed else None,
+            "per_rank_solves_per_s": {"min": count * args.steps / elapsed, "max": count * args.steps / fastest},
             "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,
+                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": ctr["traffic"],
+                         "mfma_busy_frac": ctr["mfma_busy_frac"], "counters_from": ctr["counters_from"],
                          "kernel": mpc.kernel_name, "kernel_form": kernel_form(mpc, B, dev),
                          "kernel_us_per_launch": kernel_ms * 1e3,
                          "alg_flops_per_solve": F_ALG[args.config], "alg_bytes_per_solve": BYTES_ALG[args.config],
@@ -281,15 +341,19 @@ def main():
             one.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, inputs)
+            out["cpu_structured"] = cpu_structured(args.config, inputs)
 
     # BASELINE.json configs[2..4] at full size, appended to the same line (every rank runs its own slice; `value` stays
     # on configs[1]).  Skipped when the caller picked a non-default workload itself.
     mpc.close()
-    default_line = args.config == "paper" and args.workload == "hover" and B == 256
     if default_line and not args.no_extra:
         extra = []
-        for spec in EXTRA_CONFIGS:
-            rec = measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, world, distributed)
+        specs = EXTRA_CONFIGS
+        if multi:     # configs[3] is the headline here; the 256-per-GPU hover figure of the N = 1 line moves down here
+            specs = ({"name": "configs[1] slice: batch=256 hover initial states per GPU", "config": "paper", "workload": "hover",
+                      "batch": 256, "steps": 200, "warmup": 20},) + tuple(sp for sp in EXTRA_CONFIGS if "global_total" not in sp)
+        for spec in specs:
+            rec = measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, world, distributed, red_dev)
             if rank == 0:
                 extra.append(rec)
         if rank == 0:

@@ -382,6 +382,9 @@ typedef struct {
     /* dense assembly buffers */
     double *Hd, *gd, *Acd, *lod, *hid;
     int last_iters, last_polished, last_rho_updates;
+    /* warm start (IMPCProblem.cpp:140 setWarmStart(true)): the previous solve's primal / dual (unscaled) and rho */
+    int warm, have_prev;
+    double *xw, *yw, rho_prev;
 } ws_t;
 
 static void spmv_A(const ws_t* w, const double* x, double* y) { /* y = A x (scaled values) */
@@ -459,6 +462,7 @@ void vso_workspace_free(void* p) {
     free(w->Px); free(w->Ax); free(w->q); free(w->l); free(w->u); free(w->D); free(w->E); free(w->Dinv); free(w->Einv);
     free(w->rho_vec); free(w->rho_inv); free(w->x); free(w->z); free(w->y); free(w->xprev); free(w->zprev); free(w->xt);
     free(w->zt); free(w->rhs); free(w->tmpn); free(w->tmpm); free(w->Axv); free(w->Pxv); free(w->Aty);
+    free(w->xw); free(w->yw);
     free(w);
 }
 
@@ -639,10 +643,16 @@ int vso_solve(void* wsp, const double* in, double* x, double* y, int* iters, int
     memcpy(w->l, w->lod, sizeof(double) * m);
     memcpy(w->u, w->hid, sizeof(double) * m);
     scale_problem(w);
-    double rho = OSQP_RHO;
+    const int warm = w->warm && w->have_prev;
+    double rho = warm ? w->rho_prev : OSQP_RHO;   /* OSQP keeps the adapted rho between solves */
     set_rho(w, rho);
     if (kkt_refactor(w) != 0) return 3;
     memset(w->x, 0, sizeof(double) * n); memset(w->z, 0, sizeof(double) * m); memset(w->y, 0, sizeof(double) * m);
+    if (warm) {   /* osqp_warm_start: x, y of the previous solve in the new scaling, z = A x */
+        for (int i = 0; i < n; ++i) w->x[i] = w->Dinv[i] * w->xw[i];
+        for (int i = 0; i < m; ++i) w->y[i] = w->cscale * w->Einv[i] * w->yw[i];
+        spmv_A(w, w->x, w->z);
+    }
     int status = 2, it = 0, rho_updates = 0;
     res_t r = {0, 0, 0, 0};
     for (it = 1; it <= OSQP_MAX_ITER; ++it) {
@@ -685,6 +695,12 @@ int vso_solve(void* wsp, const double* in, double* x, double* y, int* iters, int
     if (pol) r = residuals(w, w->x, w->z, w->y);
     for (int i = 0; i < n; ++i) x[i] = w->D[i] * w->x[i];
     if (y) for (int i = 0; i < m; ++i) y[i] = w->E[i] * w->y[i] / w->cscale;
+    if (w->warm) {
+        for (int i = 0; i < n; ++i) w->xw[i] = w->D[i] * w->x[i];
+        for (int i = 0; i < m; ++i) w->yw[i] = w->E[i] * w->y[i] / w->cscale;
+        w->rho_prev = rho;
+        w->have_prev = 1;
+    }
     if (iters) *iters = it;
     if (polished) *polished = pol;
     if (res2) { res2[0] = r.prim; res2[1] = r.dual; }
@@ -706,12 +722,29 @@ int vso_max_threads(void) {
  * reference's initSolver happens once).  Stops after `budget_s`.  Returns elapsed seconds; *done = instances solved,
  * x_out (may be NULL) receives the primal of every solved instance, stats[0..2] = mean iterations, polished
  * fraction, solved fraction. */
+void vso_set_warm_start(void* wsp, int on) {
+    ws_t* w = (ws_t*)wsp;
+    w->warm = on ? 1 : 0;
+    w->have_prev = 0;
+    if (on && w->xw == NULL) { w->xw = (double*)calloc(w->n, sizeof(double)); w->yw = (double*)calloc(w->m, sizeof(double)); }
+}
+
+double vso_time_batch2(const vso_config* c, const double* in, int batch, int threads, double budget_s, int* done,
+                       double* x_out, double* stats, int warm);
 double vso_time_batch(const vso_config* c, const double* in, int batch, int threads, double budget_s, int* done,
                       double* x_out, double* stats) {
+    return vso_time_batch2(c, in, batch, threads, budget_s, done, x_out, stats, 0);
+}
+
+/* warm != 0: every worker warm-starts an instance from the solution (x, y, rho) of the instance it solved before, as the
+ * reference does from tick to tick (IMPCProblem.cpp:140); the instances of a batch are neighbouring draws, not consecutive
+ * ticks, so this is an upper bound on what a closed loop gains. */
+double vso_time_batch2(const vso_config* c, const double* in, int batch, int threads, double budget_s, int* done,
+                       double* x_out, double* stats, int warm) {
     const int nv = n_var(c), nin = n_in(c);
     if (threads < 1) threads = 1;
     void** ws = (void**)malloc(sizeof(void*) * threads);
-    for (int t = 0; t < threads; ++t) ws[t] = vso_workspace_create(c);
+    for (int t = 0; t < threads; ++t) { ws[t] = vso_workspace_create(c); if (warm) vso_set_warm_start(ws[t], 1); }
     int ndone = 0;
     long sum_it = 0; int sum_pol = 0, sum_ok = 0;
     const double t0 = now_s();

@@ -7,6 +7,7 @@ import re
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd"
 
 
 def header_functions():
@@ -103,3 +104,24 @@ def test_product_path_does_not_touch_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "vsmpc_ref" not in txt and "liboracle" not in txt, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+
+
+def test_build_adds_a_horizon_from_the_environment(tmp_path, solver_mod):
+    """Row a14: the horizon table is a build-time input (the reference sizes itself from its XML at run time,
+    variableSamplingMPC.cpp:24-45).  VSMPC_HORIZONS adds an instantiation: build.horizons() parses it, and a library built
+    with an extra horizon (tools/quick_build.sh: a copy of the sources, the tracked table is left alone) carries the solve
+    kernel for it.  Compile-only: vsmpc_create needs a device."""
+    import importlib
+    import subprocess
+    build = importlib.import_module(PKG + ".build")
+    os.environ["VSMPC_HORIZONS"] = "17,7,12;25,10,18"
+    try:
+        assert build.horizons() == ((17, 7, 12), (25, 10, 18))
+    finally:
+        del os.environ["VSMPC_HORIZONS"]
+    assert build.horizons() == build.DEFAULT_HORIZONS
+    res = subprocess.run([os.path.join(ROOT, "tools", "quick_build.sh"), "25,10,18"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lib = os.path.join(ROOT, "exp", "quick", "libvsmpc.so")
+    syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
+    assert "solve_kernel<vsmpc::Dims<25, 10, 18>" in syms and "Dims<17, 7, 12>" not in syms

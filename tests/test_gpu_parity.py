@@ -420,7 +420,8 @@ def mpc2x(solver_mod, layout):
 
 def test_horizon2x_golden_and_oracle(mpc2x, ref, synth, layout, golden_h2x):
     """BASELINE.json configs[4]: 2x horizon at halved fast-rate dt (1146 variables, 994 rows, condensed dimension 236).
-    The factor lives in a global workspace for this variant; many throttle bounds are active."""
+    The factor stays in registers + the LDS panel ring for this variant too (one workgroup per CU); many throttle bounds are
+    active."""
     cfg, rcfg = layout.horizon2x_config(), ref.horizon2x_config()
     assert mpc2x.n_var == 1146 and mpc2x.n_con == 994 and mpc2x.n_in == 414 and mpc2x.n_p == 240
     x, fm, st, it = mpc2x.solve(golden_h2x["inputs"])

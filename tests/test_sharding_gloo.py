@@ -71,3 +71,53 @@ def test_two_rank_gloo_sharding():
     for r in res:
         np.testing.assert_array_equal(r[4], full[:, :24])                               # gather restores global order
         assert r[5] == total and r[6] == 2 * total and abs(r[7] - 2e-9) < 1e-20 and r[8] == 1.5
+
+
+def _worker4(rank, world, port, per_rank, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharding")
+    synth = importlib.import_module(PKG + ".synth")
+    cfg = pkg.paper_config()
+    # the slicing bench.py --gpus N puts on its line: BASELINE configs[3], `per_rank` Monte-Carlo instances per rank
+    local = sh.rank_inputs(cfg, synth, per_rank * world, rank, world, workload="montecarlo")
+    ranks = torch.tensor([1], dtype=torch.int64)
+    dist.all_reduce(ranks, op=dist.ReduceOp.SUM)                    # bench.py's `rccl_ranks`
+    el = torch.tensor([1.0 + 0.1 * rank], dtype=torch.float64)
+    hi, lo = el.clone(), el.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    q.put((rank, local[:, :40].copy(), int(ranks.item()), float(hi.item()), float(lo.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_gloo_configs3_slicing():
+    """world_size 4 with the configs[3] slicing of bench.py's N > 1 line (rank r owns the global Monte-Carlo instances
+    [r * B, (r + 1) * B), rebuilt from per-instance seeds; here B = 6 instead of 4096): the slices tile the global batch,
+    every rank is counted by the all-reduce, and the line's max / min timing reductions pick the slowest / fastest rank."""
+    per_rank, world = 6, 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    full = synth.make_batch(pkg.paper_config(), per_rank * world, workload="montecarlo")
+    np.testing.assert_array_equal(np.concatenate([r[1] for r in res]), full[:, :40])
+    for r in res:
+        assert r[2] == world and abs(r[3] - 1.3) < 1e-12 and abs(r[4] - 1.0) < 1e-12
+    # a rank's slice does not depend on the world size it was cut for: rank 1 of 4 == instances [6, 12) of any split
+    sh = importlib.import_module(PKG + ".sharding")
+    again = sh.rank_inputs(pkg.paper_config(), synth, per_rank * 8, 1, 8, workload="montecarlo")
+    np.testing.assert_array_equal(again[:, :40], full[per_rank:2 * per_rank, :40])
