@@ -71,7 +71,15 @@ struct Dims {
     // recursions of 3 HC generator columns + NV throttle columns + the affine column per half, whose forward
     // trajectories (9 N doubles) stay in the registers of the lane that owns the column.  Needs the trajectory to fit
     // the register file and the joint rows to be tile aligned; other horizons condense with the SYRK (P1).
-    static constexpr bool STRUCT_P1 = N <= 18 && NU % 16 == 0 && 3 * HC <= 64 && NV + 1 <= 64 && NP <= 128;
+    // Long horizons (one workgroup per CU, 512 registers per lane): the generator columns beyond the 64 lanes of a
+    // wavefront (NGX of them per half) ride in the free lanes of the throttle wavefront of their half, the thrust
+    // contraction A_mom^T W is summed over the halves by LDS atomics inside the chains (no W array, no contraction
+    // phase), and the rows of that array keep only the stages some throttle column at or left of them can see.
+    static constexpr int NGEN = 3 * HC;
+    static constexpr int NGX = NGEN > 64 ? NGEN - 64 : 0;
+    static constexpr bool STRUCT_LONG = N > 18;
+    static constexpr bool STRUCT_P1 = NU % 16 == 0 && NV + 1 + NGX <= 64 &&
+                                      (STRUCT_LONG ? (NP > 128 && N <= 36) : (NGX == 0 && NP <= 128));
     static constexpr int NJPAIR = HC * (HC + 1) / 2;         // joint block pairs (row block >= column block)
     static_assert(PVT >= 1 && PVT < NT, "throttle corner");
     static_assert(N <= MAX_STAGES, "horizon too long");

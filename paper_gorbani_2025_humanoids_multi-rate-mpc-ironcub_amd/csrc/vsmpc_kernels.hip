@@ -173,11 +173,23 @@ struct Smem {
     static constexpr int oSH = oGA + 6 * D::N;
     static constexpr int oSRb = oSH + 2 * D::NJPAIR * 9;
     static constexpr int oSW3 = oSRb + 2 * (D::NV + 1) * D::HC * 3;
-    static constexpr int oSAc = oSW3 + 2 * (D::NV + 1) * (D::N - 1) * 3;
-    static constexpr int oSRefC = oSAc + (D::NV + 1) * (D::N - 1) * 4;
-    static constexpr int oSZero = oSRefC + 12 * D::NREF;
+    // long horizons (Dims::STRUCT_LONG) have no sW3: the chains add A_mom^T W straight into sAc (LDS atomics, two addends
+    // per word: order independent).  A row of sAc keeps the stages i' = i - 1 >= ac_first(row) only: the tile columns at or
+    // left of a throttle row before the v_0 block all start at stage NS or later, and tau_i = 0 up to a column's first stage
+    static constexpr int oSAc = oSW3 + (D::STRUCT_LONG ? 0 : 2 * (D::NV + 1) * (D::N - 1) * 3);
+    static constexpr int AC_SHORT = D::STRUCT_LONG ? D::NV - NTH : 0;   // rows [0, AC_SHORT) are short
+    static constexpr int AC_NSH = D::STRUCT_LONG ? D::NS : 0;           // first stored i' of a short row
+    VS_HD static constexpr int ac_first(int cr) { return cr < AC_SHORT ? AC_NSH : 0; }
+    VS_HD static constexpr int ac_off(int cr) {   // offset of row cr's first stored stage (4 doubles per stage)
+        return cr < AC_SHORT ? cr * (D::N - 1 - AC_NSH) * 4 : (AC_SHORT * (D::N - 1 - AC_NSH) + (cr - AC_SHORT) * (D::N - 1)) * 4;
+    }
+    static constexpr int sizeAc = ac_off(D::NV + 1);
+    static constexpr int oSRefC = oSAc + sizeAc;
     static constexpr int sizeZero = 3 * D::N > 12 * D::NREF ? 3 * D::N : 12 * D::NREF;
-    static constexpr int endP1s = oSZero + sizeZero;
+    // the zeros: long horizons borrow the (not yet used) w and z vectors of P3..P5
+    static constexpr int oSZero = D::STRUCT_LONG ? oW : oSRefC + 12 * D::NREF;
+    static_assert(!D::STRUCT_LONG || sizeZero <= 2 * D::NP, "zeros fit the w and z vectors");
+    static constexpr int endP1s = D::STRUCT_LONG ? oSRefC + 12 * D::NREF : oSZero + sizeZero;
     static constexpr int total_syrk = oR + (sizeY > sizeM ? sizeY : sizeM);
     static constexpr int total_struct = D::STRUCT_P1 ? (endP1s > oR + sizeM ? endP1s : oR + sizeM) : total_syrk;
     // both forms share one carve-up; a horizon with the structured form never launches the SYRK form unless asked to
@@ -1384,11 +1396,17 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
     }
     const double s01 = uniform_f64(sA[(hr0 + 0) * NX + hr0 + 1]), s02 = uniform_f64(sA[(hr0 + 0) * NX + hr0 + 2]),
                  s12 = uniform_f64(sA[(hr0 + 1) * NX + hr0 + 2]);
-    // lane -> column
-    constexpr int NLIVE = KIND == 0 ? 3 * HC : NV + 1;
+    // lane -> column.  Long horizons (Dims::NGX > 0): the generator columns 64 .. 3 HC - 1 ride in the lanes behind the
+    // affine column of the KIND 1 wavefront of their half (unit forcing while their block is active: the activity takes
+    // the place of the thrust trajectory, everything else reads the zeros)
+    constexpr int NGX = D::NGX;
+    constexpr bool LONG = D::STRUCT_LONG;
+    constexpr int NLIVE = KIND == 0 ? (3 * HC < 64 ? 3 * HC : 64) : NV + 1 + NGX;
     const bool live = lane < NLIVE;
     const int col = live ? lane : NLIVE - 1;        // idle lanes shadow the last column and store nothing
-    const int gb = col / 3, gd = col - 3 * gb;      // KIND 0: joint block, momentum direction
+    const bool isgen = KIND == 0 || (NGX > 0 && col > NV);
+    const int gi = KIND == 0 ? col : (isgen ? 64 + col - (NV + 1) : 0);
+    const int gb = gi / 3, gd = gi - 3 * gb;        // generator: joint block, momentum direction
     const bool affl = KIND == 1 && col == NV;       // KIND 1: the affine column
     // x carries x + c_e throughout (e' = x + c_e; the offset is folded into the reference the affine column reads)
     double dir[3];
@@ -1400,7 +1418,7 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
             x[r] = 0.0; h[r] = 0.0; e[r] = 0.0;
         } else {
             const double a_q = sA[(hr0 + r) * NX + 12 + (col & 3)];
-            dir[r] = affl ? 0.0 : a_q;
+            dir[r] = affl ? 0.0 : (isgen ? (gd == r ? 1.0 : 0.0) : a_q);
             const double x0 = sm[S::oIn + VSMPC_IN_X0 + xr0 + r], h0 = sm[S::oIn + VSMPC_IN_X0 + hr0 + r],
                          e0 = sm[S::oIn + VSMPC_IN_X0 + er0 + r];
             const double ce0 = sm[S::oC + er0 + r];
@@ -1411,12 +1429,25 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
     }
     // per-lane operand rows (KIND 1), as offsets into the workgroup's LDS: the jet's thrust trajectory; the affine column
     // reads its forcing A_mom Tbar_k + c_h and the reference where every other column reads zeros (no select in the chain)
-    const int tauOff = (KIND == 1 && !affl) ? S::oJetT + col * N : S::oSZero;
+    const int tauOff = (KIND == 1 && !affl && !isgen) ? S::oJetT + col * N : S::oSZero;
     const int gaOff = affl ? S::oGA + half * 3 * N : S::oSZero;
     const int refOff = affl ? S::oSRefC : S::oSZero;
     const double* tauRow = sm + tauOff;
     const double* gaRow = sm + gaOff;
     const double* refRow = sm + refOff;
+    // long horizons: this half's thrust map and the row of sAc this lane adds to (see Smem::ac_off; the
+    // stored stage i' lies at (i' - ac_first) * 4 behind it, so the offset of stage 0 is folded in)
+    double Am[3][NTH];
+    int acFirst = 0, acOff = 0;
+    if constexpr (KIND == 1 && LONG) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int q = 0; q < NTH; ++q) Am[a][q] = sA[(hr0 + a) * NX + 12 + q];   // vector registers: the scalar file is full
+        const int cr = col <= NV ? col : NV;
+        acFirst = S::ac_first(cr);
+        acOff = S::ac_off(cr) - 4 * acFirst;
+    }
     // ---- forward: xi_{k+1} = xi_k + dt_k (K xi_k + forcing).  Only the momentum part of the trajectory is kept (3 N
     // doubles; the whole trajectory would be 18 N registers): x and e are rolled BACK in the adjoint pass, which explicit
     // Euler allows exactly up to rounding (x_m = x_{m+1} - dt_m M1 h_m, e_m = e_{m+1} - dt_m (x_m + c_e)).
@@ -1438,7 +1469,8 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
 #pragma unroll
             for (int r = 0; r < 3; ++r) f[r] = act * dir[r];
         } else {
-            const double tk = tk_n;
+            double tk = tk_n;
+            if constexpr (NGX > 0) tk = isgen ? (joint_block_of_stage<D>(k) == gb ? 1.0 : 0.0) : tk;
 #pragma unroll
             for (int r = 0; r < 3; ++r) f[r] = fma(tk, dir[r], ga_n[r]);
             if (k + 1 < N) {
@@ -1534,15 +1566,30 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
         double w[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) { w[a] = dti * nh[a]; bs[a] += w[a]; }
-        if constexpr (KIND == 1) {
+        if constexpr (KIND == 1 && !LONG) {
             if (i >= 1 && live) {
                 double* Wp = sW3 + ((half * (NV + 1) + col) * (N - 1) + (i - 1)) * 3;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) Wp[a] = w[a];
             }
         }
+        if constexpr (KIND == 1 && LONG) {
+            // A_mom[:, q]^T W_c(i), added to what the other half leaves in the same word (two addends on a zeroed word:
+            // the sum does not depend on which arrives first)
+            if (i >= 1) {
+                if (live && !isgen && i - 1 >= acFirst) {
+                    typedef __attribute__((address_space(3))) double lds_double;
+                    double* Ap = sm + S::oSAc + acOff + (i - 1) * 4;
+#pragma unroll
+                    for (int q = 0; q < NTH; ++q) {
+                        const double v = fma(Am[2][q], w[2], fma(Am[1][q], w[1], Am[0][q] * w[0]));
+                        __builtin_amdgcn_ds_atomic_fadd_f64((lds_double*)(Ap + q), v, 0, 0, false);
+                    }
+                }
+            }
+        }
         if (i < HC) {   // i is the first stage of joint block jb(i) = i (the last block spans stages HC-1 .. N-1)
-            if constexpr (KIND == 0) {
+            if (isgen) {
                 if (live && i >= gb) {
                     double* Hp = sH + (half * D::NJPAIR + i * (i + 1) / 2 + gb) * 9 + gd;
 #pragma unroll
@@ -1645,8 +1692,15 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         roff[ks] = hf[ks] * (NV + 1) * HC * 3 + kb * 3 + aa[ks];
     }
     const int kb9 = 9 * kb;
-    double raw[TPW][3][3];
-    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+    // tiles in groups of G: short horizons take all tiles of the wavefront at once (the accumulators are not live yet, so
+    // there are registers for every raw operand); long horizons (30 tiles per wavefront) go six tiles at a time
+    constexpr int G = D::STRUCT_LONG ? 6 : TPW;
+    constexpr int NGRP = (TPW + G - 1) / G;
+    static_for<0, NGRP>([&](auto gcst) __attribute__((always_inline)) {
+    constexpr int q0 = decltype(gcst)::value * G;
+    constexpr int q1 = q0 + G < TPW ? q0 + G : TPW;
+    double raw[G][3][3];
+    static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
@@ -1658,7 +1712,7 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
                 for (int ks = 0; ks < 3; ++ks) {
                     const double* Hp = sH + base + hoff[ks] + kb9 * (2 * ti + 1);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) raw[q][ks][d] = Hp[d];
+                    for (int d = 0; d < 3; ++d) raw[q - q0][ks][d] = Hp[d];
                 }
             } else if constexpr (ti < PVT) {
                 // diagonal tile: its upper block (row block 2 t, column block 2 t + 1) is the transposed lower one
@@ -1670,38 +1724,38 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
                     const double* Hp = sH + (hf[ks] * D::NJPAIR + hi * (hi + 1) / 2 + lo) * 9 + (sw ? aa[ks] : 3 * aa[ks]);
                     const int st = sw ? 3 : 1;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) raw[q][ks][d] = Hp[d * st];
+                    for (int d = 0; d < 3; ++d) raw[q - q0][ks][d] = Hp[d * st];
                 }
             } else if constexpr (tj < PVT) {
                 const int cr = 16 * (ti - PVT) + j;
                 const int crc = cr <= NV ? cr : NV;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) raw[q][ks][0] = sRb[(crc * HC + 2 * tj) * 3 + roff[ks]];
+                for (int ks = 0; ks < 3; ++ks) raw[q - q0][ks][0] = sRb[(crc * HC + 2 * tj) * 3 + roff[ks]];
             }
         }
     });
     __builtin_amdgcn_sched_barrier(0);
-    double op[TPW][3];
-    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+    double op[G][3];
+    static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
-        op[q][0] = op[q][1] = op[q][2] = 0.0;
+        op[q - q0][0] = op[q - q0][1] = op[q - q0][2] = 0.0;
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti < PVT) {
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks)
-                    op[q][ks] = fma(raw[q][ks][2], Lq[ks][2], fma(raw[q][ks][1], Lq[ks][1], raw[q][ks][0] * Lq[ks][0]));
+                    op[q - q0][ks] = fma(raw[q - q0][ks][2], Lq[ks][2], fma(raw[q - q0][ks][1], Lq[ks][1], raw[q - q0][ks][0] * Lq[ks][0]));
             } else if constexpr (tj < PVT) {
                 const bool ok = 16 * (ti - PVT) + j <= NV;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) op[q][ks] = ok ? raw[q][ks][0] : 0.0;
+                for (int ks = 0; ks < 3; ++ks) op[q - q0][ks] = ok ? raw[q - q0][ks][0] : 0.0;
             }
         }
     });
     __builtin_amdgcn_sched_barrier(0);
-    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+    static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
@@ -1710,16 +1764,19 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti < PVT) {
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[ks], op[q][ks], c, 0, 0, 0);
+                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[ks], op[q - q0][ks], c, 0, 0, 0);
             } else if constexpr (tj < PVT) {
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(op[q][ks], Lc[ks], c, 0, 0, 0);
+                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(op[q - q0][ks], Lc[ks], c, 0, 0, 0);
             }
         }
         acc[q] = c;
     });
     __builtin_amdgcn_sched_barrier(0);
-    // throttle x throttle tiles: all N - 1 operand pairs of a tile are requested before its chain starts
+    });
+    // throttle x throttle tiles: all operand pairs of a tile are requested before its chain starts.  The k-steps start at
+    // the first stage any column of the tile can see (tau_i = 0 up to a column's first stage); a row that does not store
+    // an earlier stage (Smem::ac_first) meets only such columns in the lower triangle and reads a zero there.
     static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
@@ -1727,19 +1784,28 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti >= PVT && tj >= PVT) {
+                constexpr int K0 = D::STRUCT_LONG ? tile_first_stage<D>(tj) : 0;   // first k-step (stage i' = i - 1)
+                constexpr int NK = N - 1 - K0;
                 const int cr = 16 * (ti - PVT) + j, cc = 16 * (tj - PVT) + j;
                 const bool okr = cr <= NV, okc = cc < NV && g == (cc & 3);
-                const double* Ap = sAc + (okr ? cr : NV) * (N - 1) * 4 + g;
+                const int crc = okr ? cr : NV;
+                const int rfirst = S::ac_first(crc);
+                const double* Ap = sAc + S::ac_off(crc) - 4 * rfirst + g;
                 const double* Tp = sJetT + (cc < NV ? cc : 0) * N + 1;
-                double av[N - 1], bv[N - 1];
+                double av[NK], bv[NK];
 #pragma unroll
-                for (int ks = 0; ks < N - 1; ++ks) { av[ks] = Ap[4 * ks]; bv[ks] = Tp[ks]; }
+                for (int ks = 0; ks < NK; ++ks) {
+                    const int ip = K0 + ks;
+                    if (D::STRUCT_LONG && ip < S::AC_NSH) av[ks] = ip >= rfirst ? Ap[4 * ip] : 0.0;
+                    else av[ks] = Ap[4 * ip];
+                    bv[ks] = Tp[ip];
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < N - 1; ++ks) { av[ks] = okr ? av[ks] : 0.0; bv[ks] = okc ? bv[ks] : 0.0; }
+                for (int ks = 0; ks < NK; ++ks) { av[ks] = okr ? av[ks] : 0.0; bv[ks] = okc ? bv[ks] : 0.0; }
                 d4 c = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < N - 1; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
+                for (int ks = 0; ks < NK; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
                 acc[q] = c;
             }
         }
@@ -1914,6 +1980,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     __syncthreads();   // ends P0 and the jet trajectories
     if constexpr (FORM == 1) {
         for (int e = tid; e < S::sizeZero; e += D::BLOCK) smem[S::oSZero + e] = 0.0;
+        if constexpr (D::STRUCT_LONG)   // the chains ADD into sAc
+            for (int e = tid; e < S::sizeAc; e += D::BLOCK) smem[S::oSAc + e] = 0.0;
         for (int e = tid; e < 12 * D::NREF; e += D::BLOCK) {   // reference window + c_e on the CoM / RPY rows
             const int row = e % 12;
             const double off = row < 3 ? sC[20 + row] : ((row >= 6 && row < 9) ? sC[23 + row - 6] : 0.0);
@@ -1945,8 +2013,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         VS_TOC(0);
         __syncthreads();
         VS_TOC(1);
-        p1s_contract<D>(smem, tid);
-        __syncthreads();
+        if constexpr (!D::STRUCT_LONG) {
+            p1s_contract<D>(smem, tid);
+            __syncthreads();
+        }
         VS_TOC(3);
         switch (wave) {
             case 0: p1s_entries<D, TPW, 0>(acc, smem, lane); break;

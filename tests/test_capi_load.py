@@ -114,14 +114,16 @@ def test_build_adds_a_horizon_from_the_environment(tmp_path, solver_mod):
     import importlib
     import subprocess
     build = importlib.import_module(PKG + ".build")
-    os.environ["VSMPC_HORIZONS"] = "17,7,12;25,10,18"
+    os.environ["VSMPC_HORIZONS"] = "17,7,12;13,5,8"
     try:
-        assert build.horizons() == ((17, 7, 12), (25, 10, 18))
+        assert build.horizons() == ((17, 7, 12), (13, 5, 8))
     finally:
         del os.environ["VSMPC_HORIZONS"]
     assert build.horizons() == build.DEFAULT_HORIZONS
-    res = subprocess.run([os.path.join(ROOT, "tools", "quick_build.sh"), "25,10,18"], capture_output=True, text=True)
+    out = str(tmp_path / "quick")
+    res = subprocess.run([os.path.join(ROOT, "tools", "quick_build.sh"), "13,5,8"], capture_output=True, text=True,
+                         env=dict(os.environ, QUICK_OUT=out))
     assert res.returncode == 0, res.stdout + res.stderr
-    lib = os.path.join(ROOT, "exp", "quick", "libvsmpc.so")
+    lib = os.path.join(out, "libvsmpc.so")
     syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
-    assert "solve_kernel<vsmpc::Dims<25, 10, 18>" in syms and "Dims<17, 7, 12>" not in syms
+    assert "solve_kernel<vsmpc::Dims<13, 5, 8>" in syms and "Dims<17, 7, 12>" not in syms

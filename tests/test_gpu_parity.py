@@ -418,6 +418,29 @@ def mpc2x(solver_mod, layout):
     m.close()
 
 
+def test_horizon2x_structured_and_syrk_condensing_agree(mpc2x, solver_mod, synth, layout):
+    """The long-horizon structured form (72 generator columns per half: eight of them ride with the throttle wavefront;
+    thrust contraction by LDS atomics inside the chains; sparse rows) against the SYRK form, as at the paper horizon."""
+    cfg = layout.horizon2x_config()
+    recs = np.concatenate([synth.make_batch(cfg, 24, workload="takeoff"), synth.make_batch(cfg, 24, workload="montecarlo"),
+                           synth.make_batch(cfg, 16, workload="hover")])
+    prev = mpc2x.set_kernel_form(solver_mod.KERNEL_FORM_STRUCTURED)
+    try:
+        a = mpc2x.solve(recs)
+        Ma, La = mpc2x.debug_condensed(recs[5])[:2]
+        mpc2x.set_kernel_form(solver_mod.KERNEL_FORM_SYRK)
+        b = mpc2x.solve(recs)
+        Mb, Lb = mpc2x.debug_condensed(recs[5])[:2]
+    finally:
+        mpc2x.set_kernel_form(prev)
+    nz = 236
+    assert relerr(np.tril(Ma[:nz + 1, :nz]), np.tril(Mb[:nz + 1, :nz])) < 1e-13
+    assert relerr(np.tril(La[:nz + 1, :nz]), np.tril(Lb[:nz + 1, :nz])) < 1e-11
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
+    assert relerr(a[0], b[0]) < 1e-10 and relerr(a[1], b[1]) < 1e-10
+
+
 def test_horizon2x_golden_and_oracle(mpc2x, ref, synth, layout, golden_h2x):
     """BASELINE.json configs[4]: 2x horizon at halved fast-rate dt (1146 variables, 994 rows, condensed dimension 236).
     The factor stays in registers + the LDS panel ring for this variant too (one workgroup per CU); many throttle bounds are

@@ -278,7 +278,8 @@ def test_hover_rollout_properties(ro, layout):
     import closed_loop_linearisation as cl
     M, _, rho = cl.load_fixture()      # derived by tests/closed_loop_linearisation.py, re-checked by the CPU suite
     assert abs(cl.spectral_radius(M) - rho) < 1e-12
-    assert rho < 1.02, rho                                   # slow lateral mode: at most marginally unstable
+    assert rho < 1.008, rho                                  # slow lateral mode: e-folding time 16 s (named in
+                                                             # tests/test_closed_loop_linearisation.py)
     periods = T // cfg.ratio
     gain = float(np.linalg.norm(np.linalg.matrix_power(M, periods)[6:9, :][:, 6:9], 2))   # attitude -> attitude over the run
     rpy_err0 = np.abs(st[:, layout.PS_RPY:layout.PS_RPY + 3] - pa[:, layout.PP_RPYINIT:layout.PP_RPYINIT + 3]).max(axis=1)
