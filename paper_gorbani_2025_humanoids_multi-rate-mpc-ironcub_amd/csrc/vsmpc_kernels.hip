@@ -603,8 +603,9 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < D::NT; ++p) {
+    // (a compile-time loop: the work lists below are indexed with p in constant expressions)
+    static_for<0, D::NT>([&](auto pcst) __attribute__((always_inline)) {
+        constexpr int p = decltype(pcst)::value;
         // rows under the diagonal tile and the wavefronts that share the panel (see panel_factor): one-slot streams of 48
         // rows wherever NWAVES - 1 wavefronts cover the panel, PANEL_SLOTS-slot streams for the tall panels of long horizons
         const int below = D::NP - 16 * p - 16;
@@ -654,41 +655,52 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                     }
                 }
             }
-            // trailing update M_ij -= L_ip L_jp^T for the owned tiles right of the panel; the operands of the next
-            // tile are requested before the four matrix-core instructions of the current one
-            double la[2][4], lb[2][4];
-            if (wl.ntrail[p] > 0) {
-                const int t = wl.trail[p][0] * D::NWAVES + W;
-                const double* Lip = sM + tile_off_c<D>(tab.ti[t], p) + lrow;
-                const double* Ljp = sM + tile_off_c<D>(tab.tj[t], p) + lrow;
+            // trailing update M_ij -= L_ip L_jp^T for the owned tiles right of the panel, two tiles at a time: the four
+            // matrix instructions of a tile are a dependent chain (one every ~95 cycles), two interleaved chains keep the
+            // pipe at its issue rate (one every 64; tools/microbench/lat_probe.hip).  The operands of the next pair are
+            // requested before the matrix instructions of the current one.
+            double la[2][2][4], lb[2][2][4];   // [pair parity][tile of the pair][k-step]
+            auto request = [&](auto acst) __attribute__((always_inline)) {
+                constexpr int a = decltype(acst)::value;
+                if constexpr (a < wl.ntrail[p]) {
+                    constexpr int t = wl.trail[p][a] * D::NWAVES + W;
+                    const double* Lip = sM + tile_off_c<D>(tab.ti[t], p) + lrow;
+                    const double* Ljp = sM + tile_off_c<D>(tab.tj[t], p) + lrow;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { la[0][ks] = -Lip[4 * ks]; lb[0][ks] = Ljp[4 * ks]; }
-            }
+                    for (int ks = 0; ks < 4; ++ks) { la[(a >> 1) & 1][a & 1][ks] = -Lip[4 * ks]; lb[(a >> 1) & 1][a & 1][ks] = Ljp[4 * ks]; }
+                }
+            };
+            request(std::integral_constant<int, 0>{});
+            request(std::integral_constant<int, 1>{});
+            static_for<0, (TPW + 1) / 2>([&](auto hcst) __attribute__((always_inline)) {
+                constexpr int a0 = 2 * decltype(hcst)::value, a1 = a0 + 1;
+                if constexpr (a0 < wl.ntrail[p]) {
+                    request(std::integral_constant<int, a0 + 2>{});
+                    request(std::integral_constant<int, a0 + 3>{});
+                    constexpr int q0 = wl.trail[p][a0];
+                    constexpr int q1 = a1 < wl.ntrail[p] ? wl.trail[p][a1] : q0;
 #pragma unroll
-            for (int a = 0; a < TPW; ++a) {
-                if (a < wl.ntrail[p]) {
-                    const int q = wl.trail[p][a];
-                    const int t = q * D::NWAVES + W;
-                    if (a + 1 < wl.ntrail[p]) {
-                        const int tn = wl.trail[p][a + 1] * D::NWAVES + W;
-                        const double* Lip = sM + tile_off_c<D>(tab.ti[tn], p) + lrow;
-                        const double* Ljp = sM + tile_off_c<D>(tab.tj[tn], p) + lrow;
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) { la[(a + 1) & 1][ks] = -Lip[4 * ks]; lb[(a + 1) & 1][ks] = Ljp[4 * ks]; }
+                    for (int ks = 0; ks < 4; ++ks) {
+                        acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[(a0 >> 1) & 1][0][ks], lb[(a0 >> 1) & 1][0][ks], acc[q0], 0, 0, 0);
+                        if constexpr (a1 < wl.ntrail[p])
+                            acc[q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[(a0 >> 1) & 1][1][ks], lb[(a0 >> 1) & 1][1][ks], acc[q1], 0, 0, 0);
                     }
+                    constexpr int t0 = q0 * D::NWAVES + W, t1 = q1 * D::NWAVES + W;
+                    if constexpr (tab.tj[t0] == p + 1) {  // this tile column is the next panel: hand it to LDS
+                        double* T = sM + tile_off_c<D>(tab.ti[t0], p + 1) + crow;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[a & 1][ks], lb[a & 1][ks], acc[q], 0, 0, 0);
-                    if (tab.tj[t] == p + 1) {  // this tile column is the next panel: hand it to LDS
-                        double* T = sM + tile_off_c<D>(tab.ti[t], p + 1) + crow;
+                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q0][r];
+                    }
+                    if constexpr (a1 < wl.ntrail[p] && tab.tj[t1] == p + 1) {
+                        double* T = sM + tile_off_c<D>(tab.ti[t1], p + 1) + crow;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q1][r];
                     }
                 }
-            }
+            });
             __syncthreads();
         }
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,9 +756,14 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
                 for (int w = 1; w < D::NWAVES; ++w) usum += sU[w * D::NP + row];
                 dop[ks] = sW[row] - usum;
             }
-            d4 zt = d4{0.0, 0.0, 0.0, 0.0};
+            // two accumulators, summed: two dependent pairs instead of a chain of four (~95 cycles per dependent step)
+            d4 zt = d4{0.0, 0.0, 0.0, 0.0}, zu = d4{0.0, 0.0, 0.0, 0.0};
+            zt = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[0], dop[0], zt, 0, 0, 0);
+            zu = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[1], dop[1], zu, 0, 0, 0);
+            zt = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[2], dop[2], zt, 0, 0, 0);
+            zu = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[3], dop[3], zu, 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) zt = __builtin_amdgcn_mfma_f64_16x16x4f64(xop[ks], dop[ks], zt, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) zt[i] += zu[i];
             if (r > 0) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) xop[ks] = sXinv[(r - 1) * D::TS + (g4 + 4 * ks) * 17 + j];
@@ -1784,7 +1801,7 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti >= PVT && tj >= PVT) {
-                constexpr int K0 = D::STRUCT_LONG ? tile_first_stage<D>(tj) : 0;   // first k-step (stage i' = i - 1)
+                constexpr int K0 = tile_first_stage<D>(tj);   // first k-step (stage i' = i - 1)
                 constexpr int NK = N - 1 - K0;
                 const int cr = 16 * (ti - PVT) + j, cc = 16 * (tj - PVT) + j;
                 const bool okr = cr <= NV, okc = cc < NV && g == (cc & 3);
@@ -1803,9 +1820,16 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < NK; ++ks) { av[ks] = okr ? av[ks] : 0.0; bv[ks] = okc ? bv[ks] : 0.0; }
-                d4 c = d4{0.0, 0.0, 0.0, 0.0};
+                // two accumulators: a dependent v_mfma_f64_16x16x4_f64 issues every ~95 cycles, independent ones every 64
+                // (tools/microbench/lat_probe.hip)
+                d4 c = d4{0.0, 0.0, 0.0, 0.0}, c2 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < NK; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
+                for (int ks = 0; ks < NK; ++ks) {
+                    if (ks & 1) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c2, 0, 0, 0);
+                    else c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] += c2[r];
                 acc[q] = c;
             }
         }
