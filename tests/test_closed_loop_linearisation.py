@@ -19,7 +19,7 @@ def test_fixture_matches_a_fresh_derivation():
     for i in (layout.PS_RPY, layout.PS_HLIN + 1):               # roll, lateral momentum: the slow lateral mode lives here
         col = cl.column(cfg, rcfg, ref, rm, orbit, p, traj, i, 1e-6 * scale[i])
         np.testing.assert_allclose(col, M[:, i], rtol=1e-5, atol=1e-7)
-    assert abs(cl.spectral_radius(M) - rho) < 1e-12 and 1.0 < rho < 1.008
+    assert abs(cl.spectral_radius(M) - rho) < 1e-12 and rho < 1.008
 
 
 def test_the_marginal_modes_are_the_ones_the_cost_does_not_see():
@@ -56,3 +56,14 @@ def test_the_marginal_modes_are_the_ones_the_cost_does_not_see():
         vk = np.abs(V[:, k]) / np.abs(V[:, k]).max()
         assert abs(w[k].imag) < 1e-9 and abs(w[k]) < 1.002
         assert vk[layout.PS_T:layout.PS_T + 4].max() == 1.0 or vk[layout.PS_TDES:layout.PS_TDES + 4].max() == 1.0
+    # the modes the cost does weigh contract: altitude (h_lin,z: a pair at 0.979 and a real one at 0.919 per period, i.e.
+    # time constants 4.7 s and 1.2 s) and everything the angular momentum leads
+    hlz, hang = layout.PS_HLIN + 2, slice(layout.PS_HANG, layout.PS_HANG + 3)
+    lead_of = [int(np.argmax(np.abs(V[:, k]))) for k in range(len(w))]
+    vertical = [abs(w[k]) for k in range(len(w)) if lead_of[k] == hlz]
+    assert len(vertical) >= 3 and max(vertical) < 0.985
+    assert all(abs(w[k]) < 0.6 for k in range(len(w)) if hang.start <= lead_of[k] < hang.stop)
+    # and the longitudinal twin of the lateral pair sits just inside the circle: which side of it the pair falls on is a
+    # matter of the synthetic jet geometry, not of the loop
+    hlx_pairs = [abs(w[k]) for k in range(len(w)) if lead_of[k] == layout.PS_HLIN and abs(w[k].imag) > 0.1 and abs(w[k]) > 0.9]
+    assert hlx_pairs and max(hlx_pairs) < 1.0
