@@ -513,6 +513,23 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
     return !(dmin > 0.0) || !(inv_last == inv_last);
 }
 
+// Long horizons (one wavefront per SIMD, 512 registers per lane): the accumulator tiles belong in the AGPR half of the
+// register file for all of P2..P5.  Left to itself the allocator parked about half of the 30 tiles of a wavefront in scratch
+// and reloaded them around every trailing update (1.3 GB of scratch writes per 4096-instance launch of the 2x horizon,
+// profiles/r03_v14_c4_h2x4096_summary.md).  An empty asm statement with "a" constraints on fifteen tiles at once (an asm
+// statement takes thirty operands, a read-write one counts twice) says so at the phase boundaries.
+template <int TPW>
+VS_DEV void pin_tiles_agpr(d4 (&acc)[TPW]) {
+    constexpr int G = 15;
+#pragma unroll
+    for (int b = 0; b + G <= TPW; b += G)
+        asm volatile("" : "+a"(acc[b]), "+a"(acc[b + 1]), "+a"(acc[b + 2]), "+a"(acc[b + 3]), "+a"(acc[b + 4]), "+a"(acc[b + 5]),
+                          "+a"(acc[b + 6]), "+a"(acc[b + 7]), "+a"(acc[b + 8]), "+a"(acc[b + 9]), "+a"(acc[b + 10]),
+                          "+a"(acc[b + 11]), "+a"(acc[b + 12]), "+a"(acc[b + 13]), "+a"(acc[b + 14]));
+#pragma unroll
+    for (int q = (TPW / G) * G; q < TPW; ++q) asm volatile("" : "+a"(acc[q]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // P2 + P3 for wavefront W, straight-line: the panel index and the tile table are compile-time, so every
 // "does this tile take part" decision folds away and every LDS offset is an immediate.
@@ -571,7 +588,7 @@ struct WaveLists {
     }
 };
 
-template <class D, int TPW, int W>
+template <class D, int TPW, int W, bool DEBUG>
 VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
                           double* __restrict__ sXinv, double* __restrict__ sW, double* __restrict__ dbgL, int lane,
@@ -581,17 +598,35 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
     using S = Smem<D>;
     constexpr int PVT = D::PVT;
     constexpr int GL = D::NZ & 15;  // local row of the gradient row (row NZ) in the last tile row
-    // ---- P2
+    if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
+    // ---- P2: the input-cost terms, by kind of tile (compile time).  A joint diagonal tile gets the joint weights on its
+    // diagonal, a tile of throttle rows x joint columns only the regularisation term of the gradient row, and only the
+    // throttle x throttle tiles go through the general (branchy) input_cost_term.  (Through v13 every element of every
+    // such tile went through it: 23k instructions of control flow at the 2x horizon, whose saved execution masks were what
+    // pushed scalar registers into vector lanes and accumulator tiles into scratch.)
+    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+        constexpr int q = decltype(qcst)::value;
+        constexpr int t = q * D::NWAVES + W;
+        if constexpr (t < D::NTRI) {
+            constexpr int ti = tab.ti[t], tj = tab.tj[t];
+            if constexpr (ti == tj && 16 * ti + 16 <= D::NU) {
+                const double wj = sCfg[CFG_WJ + (lane & 7)];   // (65000 + 20) on the diagonal (costsVSMPC.cpp:375-381,564-571)
 #pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        const int t = q * D::NWAVES + W;
-        if (t < D::NTRI && (tab.ti[t] == tab.tj[t] || tab.ti[t] >= PVT)) {
+                for (int r = 0; r < 4; ++r) acc[q][r] += ((lane >> 4) + 4 * r == (lane & 15)) ? wj : 0.0;
+            } else if constexpr (ti >= PVT && 16 * tj + 16 <= D::NU) {
+                if constexpr (ti == D::NT - 1) {   // the gradient row: w_reg * q_err (costsVSMPC.cpp:586-590)
+                    const double gq = sCfg[CFG_WREG] * sIn[VSMPC_IN_QERR + (lane & 7)];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[q][r] += input_cost_term<D>(sCfg, sIn, sVprev, 16 * tab.ti[t] + (lane >> 4) + 4 * r,
-                                                16 * tab.tj[t] + (lane & 15));
+                    for (int r = 0; r < 4; ++r) acc[q][r] += (16 * ti + (lane >> 4) + 4 * r == D::NZ) ? gq : 0.0;
+                }
+            } else if constexpr (ti == tj || ti >= PVT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[q][r] += input_cost_term<D>(sCfg, sIn, sVprev, 16 * ti + (lane >> 4) + 4 * r, 16 * tj + (lane & 15));
+            }
         }
-    }
+    });
+    if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
     // ---- P3: tile column 0 goes to LDS; every later column is stored by the update that completes it
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -606,6 +641,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
     // (a compile-time loop: the work lists below are indexed with p in constant expressions)
     static_for<0, D::NT>([&](auto pcst) __attribute__((always_inline)) {
         constexpr int p = decltype(pcst)::value;
+        if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);   // long horizons: the tiles stay in the AGPR half
         // rows under the diagonal tile and the wavefronts that share the panel (see panel_factor): one-slot streams of 48
         // rows wherever NWAVES - 1 wavefronts cover the panel, PANEL_SLOTS-slot streams for the tall panels of long horizons
         const int below = D::NP - 16 * p - 16;
@@ -633,7 +669,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
             double* Tpp = sM + tile_off_c<D>(p, p) + lane * 17;
 #pragma unroll
             for (int c = 0; c < 16; ++c) Tpp[c] = diag[c];
-            if (dbgL != nullptr) {
+            if (DEBUG && dbgL != nullptr) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
                     if (c <= lane) dbgL[size_t(16 * p + lane) * D::NP + 16 * p + c] = diag[c];
@@ -655,11 +691,11 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                     }
                 }
             }
-            // trailing update M_ij -= L_ip L_jp^T for the owned tiles right of the panel, two tiles at a time: the four
-            // matrix instructions of a tile are a dependent chain (one every ~95 cycles), two interleaved chains keep the
-            // pipe at its issue rate (one every 64; tools/microbench/lat_probe.hip).  The operands of the next pair are
-            // requested before the matrix instructions of the current one.
-            double la[2][2][4], lb[2][2][4];   // [pair parity][tile of the pair][k-step]
+            // trailing update M_ij -= L_ip L_jp^T for the owned tiles right of the panel; the operands of the next
+            // tile are requested before the four matrix-core instructions of the current one.  (Two tiles at a time --
+            // interleaved chains, a dependent v_mfma_f64_16x16x4_f64 issues every ~95 cycles, independent ones every 64 --
+            // measured no faster at either horizon: the panel streams bound P3, not these.)
+            double la[2][4], lb[2][4];
             auto request = [&](auto acst) __attribute__((always_inline)) {
                 constexpr int a = decltype(acst)::value;
                 if constexpr (a < wl.ntrail[p]) {
@@ -667,34 +703,23 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                     const double* Lip = sM + tile_off_c<D>(tab.ti[t], p) + lrow;
                     const double* Ljp = sM + tile_off_c<D>(tab.tj[t], p) + lrow;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { la[(a >> 1) & 1][a & 1][ks] = -Lip[4 * ks]; lb[(a >> 1) & 1][a & 1][ks] = Ljp[4 * ks]; }
+                    for (int ks = 0; ks < 4; ++ks) { la[a & 1][ks] = -Lip[4 * ks]; lb[a & 1][ks] = Ljp[4 * ks]; }
                 }
             };
             request(std::integral_constant<int, 0>{});
-            request(std::integral_constant<int, 1>{});
-            static_for<0, (TPW + 1) / 2>([&](auto hcst) __attribute__((always_inline)) {
-                constexpr int a0 = 2 * decltype(hcst)::value, a1 = a0 + 1;
-                if constexpr (a0 < wl.ntrail[p]) {
-                    request(std::integral_constant<int, a0 + 2>{});
-                    request(std::integral_constant<int, a0 + 3>{});
-                    constexpr int q0 = wl.trail[p][a0];
-                    constexpr int q1 = a1 < wl.ntrail[p] ? wl.trail[p][a1] : q0;
+            static_for<0, TPW>([&](auto acst) __attribute__((always_inline)) {
+                constexpr int a = decltype(acst)::value;
+                if constexpr (a < wl.ntrail[p]) {
+                    request(std::integral_constant<int, a + 1>{});
+                    constexpr int q = wl.trail[p][a];
+                    constexpr int t = q * D::NWAVES + W;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[(a0 >> 1) & 1][0][ks], lb[(a0 >> 1) & 1][0][ks], acc[q0], 0, 0, 0);
-                        if constexpr (a1 < wl.ntrail[p])
-                            acc[q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[(a0 >> 1) & 1][1][ks], lb[(a0 >> 1) & 1][1][ks], acc[q1], 0, 0, 0);
-                    }
-                    constexpr int t0 = q0 * D::NWAVES + W, t1 = q1 * D::NWAVES + W;
-                    if constexpr (tab.tj[t0] == p + 1) {  // this tile column is the next panel: hand it to LDS
-                        double* T = sM + tile_off_c<D>(tab.ti[t0], p + 1) + crow;
+                    for (int ks = 0; ks < 4; ++ks)
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[a & 1][ks], lb[a & 1][ks], acc[q], 0, 0, 0);
+                    if constexpr (tab.tj[t] == p + 1) {  // this tile column is the next panel: hand it to LDS
+                        double* T = sM + tile_off_c<D>(tab.ti[t], p + 1) + crow;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q0][r];
-                    }
-                    if constexpr (a1 < wl.ntrail[p] && tab.tj[t1] == p + 1) {
-                        double* T = sM + tile_off_c<D>(tab.ti[t1], p + 1) + crow;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q1][r];
+                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
                     }
                 }
             });
@@ -1878,7 +1903,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     do {                                                                                    \
         if constexpr (STAMPS) {                                                             \
             unsigned long long* st_ = late_args()->stamps;                                  \
-            if (threadIdx.x == 0) st_[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+            if (threadIdx.x == 0 && st_ != nullptr) st_[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
         }                                                                                   \
     } while (0)
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -2257,15 +2282,19 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     VS_STAMP(2);
     VS_REFRESH_IDS();
+    if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);   // long horizons: see pin_tiles_agpr
 
     // ---------------------------------------------------------------- P2 + P3 (wave-specialised, see cholesky_wave)
     constexpr int PVT = D::PVT;  // first tile row that contains a throttle row
     const int crow = (lane >> 4) * 17 + (lane & 15);  // C/D fragment: row (lane>>4)+4r, column lane&15
     const int lrow = (lane & 15) * 17 + (lane >> 4);  // A/B fragment: row lane&15, k = lane>>4
-    double* dbgM = late_args()->dbgM;
-    double* dbgL = late_args()->dbgL;
+    // The debug dumps (condensed Hessian, factor) exist in the diagnostic instantiation only (STAMPS; the launcher picks it
+    // when a dump or the stamps are asked for): in the shipped kernel their code -- input_cost_term per element, a branch
+    // around every store -- cost registers at the joins for nothing.
+    double* dbgM = STAMPS ? late_args()->dbgM : nullptr;
+    double* dbgL = STAMPS ? late_args()->dbgL : nullptr;
     double* dbgLi = dbgL != nullptr ? dbgL + size_t(inst) * D::NP * D::NP : nullptr;
-    if (dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
+    if (STAMPS && dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             if (q * D::NWAVES + wave < D::NTRI) {
@@ -2288,13 +2317,13 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(3);
     VS_REFRESH_IDS();
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        case 1: cholesky_wave<D, TPW, 1>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        case 2: cholesky_wave<D, TPW, 2>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        default: cholesky_wave<D, TPW, 3>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 0: cholesky_wave<D, TPW, 0, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 1: cholesky_wave<D, TPW, 1, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 2: cholesky_wave<D, TPW, 2, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        default: cholesky_wave<D, TPW, 3, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
     }
     static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
-    if (dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
+    if (STAMPS && dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             const int ti_q = kTileTab<D>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D>.tj[q * D::NWAVES + wave];
@@ -2312,6 +2341,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
 
     VS_STAMP(4);
     VS_REFRESH_IDS();
+    if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
     // ---------------------------------------------------------------- P4/P5 back-substitution L^T z = y
     // Row NZ of the factor holds L^-1 g, so y = -row.  The throttles sit at the end of the order, hence the
     // first tiles of the backward sweep yield the throttles of the QP with only the hold pin enforced.  If
@@ -2433,7 +2463,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_REFRESH_IDS();
 
     if (need_qp) {
+#ifndef VS_EXP_NOQP
         box_qp<D>(sFlags[3], hold);
+#endif
         __syncthreads();
         VS_STAMP(6);
         VS_REFRESH_IDS();
@@ -2626,7 +2658,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(9);
     if constexpr (STAMPS) {
         unsigned long long* st_ = late_args()->stamps;
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && st_ != nullptr) {
             t_acc[5] = __builtin_amdgcn_s_memrealtime() - rt0;
             t_acc[4] = rt0;  // absolute start (global 100 MHz counter): start skew across the workgroups of a launch
             for (int i = 0; i < 6; ++i) st_[size_t(blockIdx.x) * 16 + 10 + i] = t_acc[i];
@@ -2853,7 +2885,7 @@ hipError_t launch_solve(int variant, int form, const DevCfg& cfg, const double* 
     int id = 0;
 #define X(N, NS, HC)                                                                                                  \
     if (variant == ++id) {                                                                                            \
-        if (stamps != nullptr)                                                                                        \
+        if (stamps != nullptr || dbgM != nullptr || dbgL != nullptr)                                                  \
             return launch_solve_t<Dims<N, NS, HC>, true>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,  \
                                                          stamps, stream);                                             \
         return launch_solve_t<Dims<N, NS, HC>, false>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,     \
