@@ -493,6 +493,11 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
             const double lcj = readlane_f64(l[0], c);
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) a[s][c] = fma(-l[s], lcj, a[s][c]);
+            // where a lane carries two rows the column's updates pass through an (empty) volatile statement: volatile
+            // statements keep their order, so both row slots are updated while the broadcast is in its scalar registers.
+            // Otherwise the second slot's updates are postponed behind later pivots and every broadcast waits for them in a
+            // vector lane (v_writelane / v_readlane pairs: +30 % instructions in the panel stream of the 2x horizon)
+            if constexpr (NSLOT == 2) asm volatile("" : "+v"(a[0][c]), "+v"(a[1][c]));
         }
     }
     if (ok[0] && (!SPLIT || lane >= 16)) {  // above its diagonal the diagonal tile holds leftovers: readers mask it
