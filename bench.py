@@ -66,9 +66,16 @@ def cpu_baseline(cfg_name: str, inputs: np.ndarray, budget_s: float = 15.0):
 
 
 def kernel_form(mpc, batch, dev):
-    """How the solve kernel of this handle condenses the QP (include/vsmpc.h, vsmpc_set_kernel_form)."""
-    forced = os.environ.get("VSMPC_FORM", "")[:2]
-    structured = mpc.n_p <= 128 and forced != "sy"      # horizons with Dims::STRUCT_P1 default to it
+    """How the solve kernel of this handle condenses the QP (include/vsmpc.h, vsmpc_set_kernel_form): asked of the
+    library, not guessed -- a handle accepts form 1 only if its horizon has the structured form."""
+    from importlib import import_module
+    solver = import_module("paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd.solver")
+    try:
+        prev = mpc.set_kernel_form(solver.KERNEL_FORM_STRUCTURED)
+        mpc.set_kernel_form(prev)
+        structured = prev != solver.KERNEL_FORM_SYRK
+    except ValueError:
+        structured = False
     wgs = "two workgroups per CU" if mpc.n_p <= 128 else "one workgroup per CU"
     return (("structured condensing (forward / adjoint recursions)" if structured else "sensitivity recursion + SYRK on the matrix cores")
             + f"; 4 wavefronts, {wgs}")
