@@ -388,6 +388,7 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 #endif
 constexpr int SYRK_DIST = VS_SYRK_DIST;
 
+
 // TIED: the matrix instruction is written as inline assembly whose accumulator is a read-write operand, i.e. the result
 // lands in the registers the tile already occupies.  With the builtin the register allocator is free to put the result
 // of a chain's first instruction into fresh registers, and at the control-flow joins around the chains it then moves
@@ -448,8 +449,9 @@ VS_DEV void syrk_slot(d4& acc, const double* __restrict__ pa, const double* __re
 // the remaining lanes (48 rows and the short one-slot stream wherever three wavefronts cover the panel).  The other wavefronts read the unfactored diagonal tile while wavefront
 // w = 0 works, so in SPLIT mode the factored diagonal tile is not stored here: it is handed back in `diag` (lanes
 // 0..15 of wavefront 0) and stored by the caller after the workgroup barrier that ends the panel step.
-template <class D, int NSLOT, int NPIV, bool SPLIT = false>
-VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16]) {
+template <class D, int NSLOT, int NPIV, bool SPLIT = false, bool PLDS = false>
+VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16],
+                         double* sCol) {
     constexpr int RPW = 64 * NSLOT - 16;  // SPLIT: rows below the diagonal tile carried by one wavefront
     double* T[NSLOT];
     bool ok[NSLOT];
@@ -488,9 +490,16 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
                 inv = fast_rsqrt(d);
             }
         }
+        // PLDS (the form for two workgroups per CU): the pivot column reaches the columns c >= j + 2 through LDS -- every lane
+        // stores its slot-0 entry (entries 0..15 of the wavefront's 64-double strip are the rows of the diagonal tile), the
+        // updates read entry c with a wave-uniform address: one (often half an) instruction per column instead of a
+        // v_readlane pair.  Fewer instructions, more latency: with a second workgroup on the CU to fill the waits it is
+        // 2.7 % faster (batch 4096: 409.6 -> 398.6 us), a lone workgroup is 0.5 % slower and the 2x horizon 9 % slower, so
+        // the launcher picks it by batch size.  Only column j + 1, which the next pivot waits for, always goes through v_readlane.
+        if (PLDS && j + 2 < 16) sCol[lane] = l[0];
 #pragma unroll
         for (int c = j + 2; c < 16; ++c) {
-            const double lcj = readlane_f64(l[0], c);
+            const double lcj = PLDS ? sCol[c] : readlane_f64(l[0], c);
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) a[s][c] = fma(-l[s], lcj, a[s][c]);
             // where a lane carries two rows the column's updates pass through an (empty) volatile statement: volatile
@@ -593,11 +602,11 @@ struct WaveLists {
     }
 };
 
-template <class D, int TPW, int W, bool DEBUG>
+template <class D, int TPW, int W, bool DEBUG, bool PLDS>
 VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
                           double* __restrict__ sXinv, double* __restrict__ sW, double* __restrict__ dbgL, int lane,
-                          int crow, int lrow) {
+                          int crow, int lrow, double* sZ_) {
     constexpr TileTab<D> tab{};
     constexpr WaveLists<D, TPW, W> wl{};
     using S = Smem<D>;
@@ -654,14 +663,18 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         const int rpw = one_slot ? 48 : 64 * D::PANEL_SLOTS - 16;
         const int nshare = below <= rpw ? 1 : (below + rpw - 1) / rpw;
         double diag[16];  // factored diagonal tile of a shared panel (wavefront 0, lanes 0..15), stored after the barrier
+        // broadcast strip of this wavefront (64 doubles): the slot of X_p, which nobody writes before panel p + 1; the last
+        // panels (one wavefront each) borrow the not-yet-used z vector
+        double* sCol = p <= PVT ? sXinv + p * D::TS + 64 * W : sZ_ + 64 * W;
+        static_assert(D::TS >= 64 * D::NWAVES && D::NP >= 64, "broadcast strips");
         {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
             if (p == D::NT - 1) {
-                if (W == 0 && panel_factor<D, 1, NPIV_LAST>(sM, sInvD, p, lane, 0, diag) && lane == 0) sFlags[0] = 1;
+                if (W == 0 && panel_factor<D, 1, NPIV_LAST, false, PLDS>(sM, sInvD, p, lane, 0, diag, sCol) && lane == 0) sFlags[0] = 1;
             } else if (W < nshare) {
                 int bad;
-                if (one_slot) bad = panel_factor<D, 1, 16, true>(sM, sInvD, p, lane, W, diag);
-                else bad = panel_factor<D, D::PANEL_SLOTS, 16, true>(sM, sInvD, p, lane, W, diag);
+                if (one_slot) bad = panel_factor<D, 1, 16, true, PLDS>(sM, sInvD, p, lane, W, diag, sCol);
+                else bad = panel_factor<D, D::PANEL_SLOTS, 16, true, PLDS>(sM, sInvD, p, lane, W, diag, sCol);
                 if (W == 0 && bad && lane == 0) sFlags[0] = 1;
             }
         }
@@ -1898,7 +1911,7 @@ VS_DEV const SolveArgs* late_args() {
 // FORM selects how P1 condenses: 0 = sensitivity recursion + SYRK on the matrix cores (every horizon), 1 = structured
 // condensing (P1s, horizons with Dims::STRUCT_P1; the default there).  Everything from P2 on is the same code; the two
 // forms agree to rounding (different summation order), which tests/test_gpu_parity.py checks on the device.
-template <class D, bool STAMPS, int FORM = 0>
+template <class D, bool STAMPS, int FORM = 0, bool PLDS = false>
 __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cfg, const double* __restrict__ in, int batch,
                                                          double* xout_, double* fmout_, int* status_out_,
                                                          int* iters_out_, double* dbgM_, double* dbgL_,
@@ -2322,10 +2335,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(3);
     VS_REFRESH_IDS();
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        case 1: cholesky_wave<D, TPW, 1, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        case 2: cholesky_wave<D, TPW, 2, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
-        default: cholesky_wave<D, TPW, 3, STAMPS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow); break;
+        case 0: cholesky_wave<D, TPW, 0, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 1: cholesky_wave<D, TPW, 1, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 2: cholesky_wave<D, TPW, 2, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        default: cholesky_wave<D, TPW, 3, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
     }
     static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
     if (STAMPS && dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
@@ -2794,7 +2807,7 @@ int initial_kernel_form() {
     return (v != nullptr && v[0] == 's' && v[1] == 't') ? 1 : (v != nullptr && v[0] == 's' && v[1] == 'y') ? 2 : 0;
 }
 
-template <class D, bool STAMPS, int FORM>
+template <class D, bool STAMPS, int FORM, bool PLDS = false>
 static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
                                  unsigned long long* stamps, hipStream_t stream) {
@@ -2802,12 +2815,12 @@ static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in,
     static bool attr_set[MAX_DEVICES] = {};
     constexpr size_t lds = FORM == 1 ? Smem<D>::bytes_struct : Smem<D>::bytes;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS, FORM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS, FORM, PLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((solve_kernel<D, STAMPS, FORM>), dim3(batch), dim3(D::BLOCK), lds, stream,
+    hipLaunchKernelGGL((solve_kernel<D, STAMPS, FORM, PLDS>), dim3(batch), dim3(D::BLOCK), lds, stream,
                        cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
     return hipGetLastError();
 }
@@ -2821,9 +2834,25 @@ static hipError_t launch_solve_t(int form, const DevCfg& cfg, const double* d_in
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
     if constexpr (D::STRUCT_P1) {
-        if (form != 2)
+        if (form != 2) {
+            // two workgroups per CU once the batch exceeds the CUs: the panel streams with LDS broadcasts (see panel_factor)
+            if constexpr (D::WG_PER_CU == 2 && !STAMPS) {
+                static int cus[MAX_DEVICES] = {};
+                if (cus[dev] == 0) {
+                    int n = 0;
+                    e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                    if (e != hipSuccess) return e;
+                    cus[dev] = n > 0 ? n : 1;
+                }
+                const char* pv = getenv("VSMPC_PANEL");   // measurements: lds | readlane
+                const bool lds = pv != nullptr ? pv[0] == 'l' : batch > cus[dev];
+                if (lds)
+                    return launch_solve_f<D, STAMPS, 1, true>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
+                                                              stamps, stream);
+            }
             return launch_solve_f<D, STAMPS, 1>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
                                                 stream);
+        }
     }
     return launch_solve_f<D, STAMPS, 0>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps,
                                             stream);

@@ -289,6 +289,26 @@ def test_structured_and_syrk_condensing_agree(mpc, solver_mod, synth, layout):
         mpc.set_kernel_form(7)
 
 
+def test_panel_stream_variants_agree(mpc, synth, layout):
+    """P3's panel streams exist in two variants (panel_factor in csrc/vsmpc_kernels.hip): pivot columns broadcast with
+    v_readlane (a lone workgroup per CU) or through LDS (two workgroups per CU, picked once the batch exceeds the CU
+    count); VSMPC_PANEL overrides the choice.  Same arithmetic in the same order: bit-identical results."""
+    import os
+    cfg = layout.paper_config()
+    recs = np.concatenate([synth.make_batch(cfg, 40, workload="takeoff"), synth.make_batch(cfg, 40, workload="montecarlo")])
+    out = {}
+    try:
+        for variant in ("readlane", "lds"):
+            os.environ["VSMPC_PANEL"] = variant
+            out[variant] = mpc.solve(recs)
+    finally:
+        os.environ.pop("VSMPC_PANEL", None)
+    a, b = out["readlane"], out["lds"]
+    assert (a[2] == layout.STATUS_SOLVED).all()
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+
+
 def test_edge_cases(mpc, solver_mod, synth, layout, ref):
     cfg, rcfg = layout.paper_config(), ref.paper_config()
     # empty batch
