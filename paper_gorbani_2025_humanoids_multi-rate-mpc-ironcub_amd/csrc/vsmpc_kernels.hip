@@ -5,20 +5,22 @@
 //
 //   P0 linearise   A, Bj, Bt, c in LDS                       (systemDynamicsVSMPC.cpp:79-103,288-319,384-429)
 //   P1 condense    jet thrust sensitivities first (one two-state recursion per throttle column, four for the affine
-//                  column), then the sensitivity recursion in registers: thread (half, col) carries the
-//                  linear-momentum half (p, h_lin, e_pos) or the angular half (rpy, h_ang, e_rpy) of
-//                  one condensed column; two nodes (36 weighted rows = 9 exact MFMA k-steps) per pass;
-//                  C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, accumulators in registers, every pass a
-//                  straight-line sequence of per-tile chains (compile-time slot count).  Two forms: throughput (four
-//                  wavefronts, two workgroups per CU) and latency (eight wavefronts, the recursion of the next pass
-//                  beside the SYRK of this one; batches of at most one instance per CU)
+//                  column).  Structured form (P1s, the default where Dims::STRUCT_P1): forward / adjoint recursions on
+//                  three generator columns per joint block, the throttle columns and the affine column, one lane per
+//                  (column, half), trajectory in registers; the tile entries of C formed on the matrix cores from the
+//                  block sums the chains leave in LDS -- O(N^2) work.  SYRK form (every horizon; vsmpc_set_kernel_form):
+//                  the sensitivity recursion in registers, thread (half, col) carries the linear-momentum half (p, h_lin,
+//                  e_pos) or the angular half (rpy, h_ang, e_rpy) of one condensed column; two nodes (36 weighted rows =
+//                  9 exact MFMA k-steps) per pass; C = sum_k Y_k^T Y_k with v_mfma_f64_16x16x4_f64, every pass a
+//                  straight-line sequence of per-tile chains (compile-time slot count).  Accumulators in registers
+//                  from here to P5; 256 threads, two workgroups per CU at the paper horizon
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
 //   P3 cholesky    right-looking LL^T on 16x16 tiles; the trailing matrix AND the finished factor stay in registers,
 //                  LDS holds a ring of two panel columns + the throttle corner; trailing updates on MFMA; a panel is
-//                  factored lane = row (pivots broadcast with v_readlane) by up to three wavefronts that each repeat
-//                  the diagonal tile and take 48 of the rows below; a wavefront without panel rows inverts the
-//                  finished diagonal tiles (X_p)
+//                  factored lane = row (pivots broadcast with v_readlane, or through LDS once two workgroups share a
+//                  CU) by up to three wavefronts that each repeat the diagonal tile and take 48 of the rows below; a
+//                  wavefront without panel rows inverts the finished diagonal tiles (X_p)
 //   P4 box QP      backward pass over the throttle tiles with only the hold pin; only if a bound is violated: block
 //                  principal pivoting in one wavefront, dual form on P = X^T X for few violated bounds, primal form
 //                  on the Schur complement otherwise, small systems in registers   (constraintsVSMPC.cpp:338-365)
@@ -30,10 +32,10 @@
 // FP64 throughout.  The un-condensed KKT system the reference hands to OSQP has condition number
 // ~1e12; the condensed Hessian factored here is benign (1e2..1e3).
 //
-// Measured on MI355X (profiles/r01_microbench_*.txt): v_mfma_f64_16x16x4_f64 issues every 64 cycles per
-// SIMD (77.7 TFLOP/s chip-wide, already with one wavefront per SIMD); FP64 VALU work does not hide under
-// it (shared FP64 datapath); one FP64 FMA costs ~5.7 cycles for a lone wavefront, v_readlane pair + FMA
-// ~21.6.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
+// Measured on MI355X (profiles/r01_microbench_*.txt, tools/microbench/lat_probe.hip): v_mfma_f64_16x16x4_f64 issues
+// every 64 cycles per SIMD (77.7 TFLOP/s chip-wide, already with one wavefront per SIMD), a dependent one every ~95; FP64
+// VALU work does not hide under it (shared FP64 datapath); a dependent vector instruction issues every 8-10 cycles, a
+// v_readlane takes ~32 cycles to land, v_readlane pair + FMA ~21.6 per update.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
 // streams carry nothing but operand loads.
 #include <cstdlib>
 #include <type_traits>
@@ -1411,11 +1413,14 @@ VS_DEV void box_qp(int n_violated, bool hold) {
 // pi_c(i) the column's forcing profile: Lambda[:, q] while jb(i) = b for the joint column (b, q), A_mom[:, q] tau_i for a
 // throttle column (tau = its jet's thrust trajectory from P1a).  A joint block only ever enters through the three momentum
 // directions, so 3 generator columns per block (unit forcing e_d) stand for its 8 joint columns: one lane per
-// (generator | throttle column | affine column) and half runs the forward recursion with the trajectory held in
-// REGISTERS (9 N doubles), then the adjoint recursion backwards, and leaves in LDS
+// (generator | throttle column | affine column) and half runs the forward recursion with the momentum part of the
+// trajectory held in REGISTERS (3 N doubles; x and e are rolled back in the adjoint pass), then the adjoint recursion
+// backwards, and leaves in LDS
 //     sH [half][pair(bc <= br)][a][d]  = sum_{i in br} W_gen(bc, d)(i)[a]          (KIND 0, generator lanes)
 //     sRb[half][c][b][a]               = sum_{i in b} W_c(i)[a]                     (KIND 1, throttle / affine lanes)
-//     sAc[half][c][i - 1][q]           = A_mom[:, q]^T W_c(i),  i >= 1              (tau_0 = 0)
+//     sW3[half][c][i - 1][a]           = W_c(i)[a],  i >= 1  (tau_0 = 0; short horizons: p1s_contract sums
+//                                        sAc[c][i - 1][q] = sum_half A_mom[:, q]^T W_c(i) from it; long horizons add
+//                                        their half of sAc straight from the chain with LDS atomics and have no sW3)
 // from which p1s_entries forms every entry of C directly in the accumulator layout of the owning wavefront:
 //     joint x joint        Lambda[:, qr]^T sH Lambda[:, qc]                               (summed over the halves)
 //     throttle x joint     Lambda[:, qc]^T sRb[cr][bc]
@@ -1424,7 +1429,7 @@ VS_DEV void box_qp(int n_violated, bool hold) {
 // (3.8 MFLOP executed).  The affine column carries x0, c and the reference: W_aff(i) = gamma_i.
 // ------------------------------------------------------------------------------------------------
 // a wave-uniform double moved into scalar registers (v_fma_f64 takes one scalar operand pair): the coefficient matrices of
-// a chain cost no vector registers, which is what lets the 9 N doubles of the trajectory stay in them
+// a chain cost no vector registers, which is what lets the trajectory stay in them
 VS_DEV double uniform_f64(double x) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
@@ -2481,9 +2486,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_REFRESH_IDS();
 
     if (need_qp) {
-#ifndef VS_EXP_NOQP
         box_qp<D>(sFlags[3], hold);
-#endif
         __syncthreads();
         VS_STAMP(6);
         VS_REFRESH_IDS();
