@@ -389,6 +389,9 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 #define VS_SYRK_UNROLL 1
 #endif
 constexpr int SYRK_DIST = VS_SYRK_DIST;
+#ifndef VS_KMID
+#define VS_KMID 24
+#endif
 
 
 // TIED: the matrix instruction is written as inline assembly whose accumulator is a read-write operand, i.e. the result
@@ -933,6 +936,7 @@ template <class D>
 struct XTiles {
     static constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
     static constexpr int KMAX = SMALL_SOLVE_MAX;   // largest system solved in registers (the accumulator tiles are in VGPRs here)
+    static constexpr int KMID = 0;                 // no mid-size register solver: no registers for it
     const double* X6;
     const double* sXr;
     VS_DEV double col(int j, int r, int n) const {
@@ -957,6 +961,7 @@ template <class D>
 struct XDense {
     static constexpr int NVS = D::NV + 1;
     static constexpr int KMAX = 10;                // accumulator tiles live in AGPRs at these horizons: room for 10 x 10
+    static constexpr int KMID = VS_KMID;           // and for the compact row-per-lane solver up to KMID x KMID (mid_spd_solve)
     const double* sXd;
     VS_DEV double col(int j, int r, int n) const { return j < n ? sXd[j * NVS + r] : 0.0; }
     VS_DEV double pcol(int b, int r, int n) const {
@@ -972,6 +977,60 @@ struct XDense {
 };
 
 // ------------------------------------------------------------------------------------------------
+// KMAX < K <= KMID active bounds: P_AA mu = rhs_A in registers, rows where they are (lane r = throttle r keeps
+// a[q] = P[r][idx_q] for the K active indices idx_0 < idx_1 < ...: compact COLUMNS, scattered rows), Gaussian elimination
+// without pivoting (SPD) with the pivot rows broadcast by v_readlane from lane idx_j (a scalar).  ~5 instructions per
+// update against ~12 for the elimination on an LDS copy (three LDS operations per update) and ~2.8 k instructions for one
+// iteration of the primal form on all 44 throttles, which is what instances with more than 16 violated bounds ran
+// before.  Lane idx_q returns mu_q, every other lane 0.
+// ------------------------------------------------------------------------------------------------
+template <int KMID, int NVS>
+VS_DEV double mid_spd_solve(int ka, const double* __restrict__ sP, unsigned long long Amask, double bb, int lane, bool isA,
+                            int& bad) {
+    int idx[KMID];
+    {
+        unsigned long long m = Amask;
+#pragma unroll
+        for (int q = 0; q < KMID; ++q) {
+            idx[q] = m ? __ffsll((long long)m) - 1 : 0;   // (wave uniform: scalar registers)
+            m &= m - 1;
+        }
+    }
+    const int rank = __popcll(Amask & ((1ull << lane) - 1ull));   // compact position of this lane's throttle
+    double a[KMID];
+#pragma unroll
+    for (int q = 0; q < KMID; ++q) a[q] = sP[idx[q] * NVS + lane];   // P[lane][idx_q] (symmetric); garbage beyond ka, unused
+#pragma unroll
+    for (int j = 0; j < KMID; ++j) {
+        if (j < ka) {   // (guards, not `break`: an early exit keeps the loops rolled and puts a[] in scratch -- measured 2.3x slower)
+            const double piv = readlane_f64(a[j], idx[j]);
+            bad |= !(piv > 0.0);
+            const double ip = fast_rcp(piv);
+            const double bj = readlane_f64(bb, idx[j]);
+            const double f = (isA && rank > j) ? a[j] * ip : 0.0;
+            bb = fma(-f, bj, bb);
+#pragma unroll
+            for (int c = j + 1; c < KMID; ++c) {
+                if (c < ka) {
+                    const double pc = readlane_f64(a[c], idx[j]);
+                    a[c] = fma(-f, pc, a[c]);
+                }
+            }
+        }
+    }
+    double mu = 0.0;
+#pragma unroll
+    for (int j = KMID - 1; j >= 0; --j) {
+        if (j < ka) {
+            const double xj = readlane_f64(bb, idx[j]) * fast_rcp(readlane_f64(a[j], idx[j]));
+            mu = (lane == idx[j]) ? xj : mu;
+            bb = (isA && rank < j) ? fma(-a[j], xj, bb) : bb;
+        }
+    }
+    return mu;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dual active-set iteration of the box QP by ONE wavefront (lane = throttle).  With N = the throttles that are not
 // pinned by the hold, P = S_NN^-1 = X^T X and v_u = the sweep's solution (sZ), fixing the set A at its bounds b_A gives
 // mu = P_AA^-1 (v_u,A - b_A),  v_N = v_u,N - P[:,A] mu,  gradient_A = -mu.  Only the columns of P some active set needs
@@ -981,9 +1040,10 @@ struct XDense {
 template <class D, class XA>
 VS_DEV void dual_active_set(const XA& xa, bool hold, int lane, double* __restrict__ sSv, double* __restrict__ sQP,
                             const double* __restrict__ sSvec, const double* __restrict__ sVprev,
-                            const double* __restrict__ sCfg, double* __restrict__ sZ, int* __restrict__ sFlags) {
+                            const double* __restrict__ sCfg, double* __restrict__ sZ, int* __restrict__ sFlags,
+                            unsigned long long have0 = 0ull) {
     constexpr int NVS = D::NV + 1;          // row stride of the LDS work arrays
-    double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far
+    double* sP = sSv;                       // sP[b * NVS + i] = P[i][b] for the columns b formed so far (have0: on entry)
     double* sK = sQP;                       // working copy of P_AA
     const int r = lane < D::NV ? lane : D::NV - 1;  // lanes >= NV shadow the last row (results unused)
     const bool valid = lane < D::NV;
@@ -1007,7 +1067,7 @@ VS_DEV void dual_active_set(const XA& xa, bool hold, int lane, double* __restric
         best = __popcll(__ballot(vlo || vhi));
         if (vlo || vhi) state = vlo ? -1 : 1;
     }
-    unsigned long long have = 0ull;
+    unsigned long long have = have0;
     for (int it = 1; it < AS_MAX_ITER; ++it) {
         iters = it + 1;
         const bool isA = inN && state != 0;
@@ -1029,6 +1089,8 @@ VS_DEV void dual_active_set(const XA& xa, bool hold, int lane, double* __restric
         } else if (ka <= XA::KMAX) {
             // few active bounds: solved redundantly in every lane on wave-uniform values
             mu = small_spd_solve_n<D::NV + 1, XA::KMAX>(ka, sP, Amask, bb, lane, bad);
+        } else if (XA::KMID > 0 && ka <= XA::KMID) {
+            if constexpr (XA::KMID > 0) mu = mid_spd_solve<XA::KMID, D::NV + 1>(ka, sP, Amask, bb, lane, isA, bad);
         } else {
             // K = P_AA (working copy); Gaussian elimination without pivoting (SPD) over the active indices
             if (isA) {
@@ -1122,7 +1184,7 @@ VS_DEV void box_qp(int n_violated, bool hold) {
     constexpr int DUAL_MAX_ACTIVE = 10;
     constexpr bool DUAL3 = S::DUAL3;
 #ifndef VS_DUAL3_MAX
-#define VS_DUAL3_MAX 16
+#define VS_DUAL3_MAX 24
 #endif
     const bool few = n_violated <= (DUAL3 ? VS_DUAL3_MAX : DUAL_MAX_ACTIVE);   // few saturated throttles: dual form
     (void)sQP; (void)sXinv; (void)sInvD;
@@ -1272,9 +1334,45 @@ VS_DEV void box_qp(int n_violated, bool hold) {
             if (ti < R2) xd(2, 0)[ti * NVS + tj] = -a;
         }
         __syncthreads();
+        {   // round 6: ALL of P = X_N^T X_N on the matrix cores (six lower 16 x 16 tiles, twelve k-steps each, over the four
+            // wavefronts): ~2 k cycles once, where a column formed on demand inside the iteration costs one wavefront ~1.3 k
+            // and an instance needs eight to twelve of them.  sP[b * NVS + i] = P[i][b], both triangles.
+            static_assert(D::NV <= 48, "three tile rows");
+            const int n = hold ? D::NV - 4 : D::NV;
+            const int g = lane >> 4, m = lane & 15;
+#pragma unroll 1
+            for (int t = wave; t < 6; t += D::NWAVES) {
+                const int ta = t < 1 ? 0 : (t < 3 ? 1 : 2), tb = t - ta * (ta + 1) / 2;
+                const int ca = 16 * ta + m, cb = 16 * tb + m;
+                double xa_[12], xb_[12];
+#pragma unroll
+                for (int ks = 0; ks < 12; ++ks) {
+                    const int j = 4 * ks + g;
+                    const double va = sXd[j * NVS + ca], vb = sXd[j * NVS + cb];   // (in range of the LDS for every lane)
+                    xa_[ks] = (j < n && ca < D::NV) ? va : 0.0;
+                    xb_[ks] = (j < n && cb < D::NV) ? vb : 0.0;
+                }
+                d4 c0 = d4{0.0, 0.0, 0.0, 0.0}, c1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 12; ks += 2) {
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_[ks], xb_[ks], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_[ks + 1], xb_[ks + 1], c1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ta + g + 4 * r;
+                    const double pv = c0[r] + c1[r];
+                    if (i < D::NV && cb < D::NV) {
+                        sSv[cb * NVS + i] = pv;
+                        sSv[i * NVS + cb] = pv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
         if (wave == 0) {
             const XDense<D> xa{sXd};
-            dual_active_set<D>(xa, hold, lane, sSv, sQP, sSvec, sVprev, sCfg, sZ, sFlags);
+            dual_active_set<D>(xa, hold, lane, sSv, sQP, sSvec, sVprev, sCfg, sZ, sFlags, ~0ull);
         }
        }
       } else {
