@@ -153,6 +153,8 @@ struct Smem {
     static constexpr bool DUAL3 = !DUALQP && D::NT - 3 == D::PVT && D::NU % 16 == 0 && D::NV > 32 && D::NV <= 48;
     static constexpr int oQP = oSv + D::NV * NVS;    // dual form: K | rows 16.. of X (DUALQP); K | X | two scratch tiles (DUAL3)
     static constexpr int sizeQP = DUALQP ? D::NV * NVS + (D::NV - 16) * NVS : (DUAL3 ? 2 * D::NV * NVS + 2 * D::TS : 0);
+    static constexpr int oDual3T0 = oQP + 2 * D::NV * NVS;   // DUAL3: two tile-shaped scratches behind K and X
+    static constexpr int oDual3T1 = oDual3T0 + D::TS;
     // per-wavefront partial sums of L^T z, NP each.  The box-QP arrays are dead by then: where the dense X would not fit
     // beside them (DUAL3) the two overlap
     static constexpr int oU = DUAL3 ? oR : oQP + sizeQP;
@@ -687,6 +689,13 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         // until the update of THIS panel hands column p+1 over): X_0..X_PVT for P5 and the dual box QP
         if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p >= 1 && p - 1 < S::NXT)
             tile_inverse<D>(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
+        // three throttle tile rows: the box QP also wants the inverses of the other two corner diagonal tiles.  The second
+        // one here, into the tile-shaped scratch the QP reads it from (that part of the ring is dead since the last joint
+        // panel); the third one after P3 (solve_kernel).  ~4 k cycles each that used to sit at the top of the box QP.
+        if constexpr (S::DUAL3) {
+            if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p - 1 == D::PVT + 1)
+                tile_inverse<D>(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sM + (S::oDual3T0 - S::oM), lane);
+        }
         __syncthreads();
         if (W == 0 && p < D::NT - 1 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
             double* Tpp = sM + tile_off_c<D>(p, p) + lane * 17;
@@ -1259,8 +1268,9 @@ VS_DEV void box_qp(int n_violated, bool hold) {
         //   X20 = -X2 (L20 X0 + L21 X10);  one 16x16 entry per thread and product, four barrier-separated rounds.
         constexpr int NVS = D::NV + 1, R2 = D::NV - 32;        // throttle rows in the last tile row
         double* sXd = sQP + D::NV * NVS;                        // sXd[j * NVS + i] = X[j][i]
-        double* sT0 = sXd + D::NV * NVS;                        // L10 X0, later L20 X0 + L21 X10
-        double* sT1 = sT0 + D::TS;                              // L21 X1 (both tile-sized: the inverses pass through them)
+        double* sT0 = smem + S::oDual3T0;                       // X1 on entry (from P3); L10 X0, later L20 X0 + L21 X10
+        double* sT1 = smem + S::oDual3T1;                       // X2 on entry (formed beside the sweep); L21 X1
+        static_assert(S::oDual3T0 == S::oQP + 2 * D::NV * NVS, "scratch tiles behind K and X");
         const double* L10 = Lb + tile_off<D>(PV + 1, PV);
         const double* L20 = Lb + tile_off<D>(PV + 2, PV);
         const double* L21 = Lb + tile_off<D>(PV + 2, PV + 1);
@@ -1268,19 +1278,17 @@ VS_DEV void box_qp(int n_violated, bool hold) {
         const int ti = tid >> 4, tj = tid & 15;                 // entry (ti, tj) of a 16 x 16 product
         auto xd = [&](int blk_r, int blk_c) { return sXd + (16 * blk_r) * NVS + 16 * blk_c; };   // block of X, row stride NVS
         for (int e = tid; e < D::NV * NVS; e += D::BLOCK) sXd[e] = 0.0;
-        if (tid < D::NV) {   // s = L22 (L^-1 g)_v: its largest entry scales the release tolerance
-            double sum = 0.0;
-            for (int k = 0; k <= tid; ++k)
-                sum += Lb[lower_at<D>(D::NU + tid, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
-            sSvec[tid] = sum;
+        if (tid < 4 * D::NV) {   // s = L22 (L^-1 g)_v (its largest entry scales the release tolerance): four threads per row,
+            const int i = tid >> 2, part = tid & 3;   // every fourth term each -- one thread per row was a 44-step serial loop
+            double sum = 0.0;                         // (4.4 k cycles) in front of the first barrier
+            for (int k = part; k <= i; k += 4)
+                sum += Lb[lower_at<D>(D::NU + i, D::NU + k)] * Lb[lower_at<D>(D::NZ, D::NU + k)];
+            sSv[tid] = sum;                           // partial sums: P's array is not in use before round 6
         }
         __syncthreads();
-        // round 1: diagonal blocks (wavefronts 1, 2 invert; wavefront 0 copies X0; wavefront 3 forms max |s|), T10 later
-        if (wave == 1) {
-            tile_inverse<D>(Lb + tile_off<D>(PV + 1, PV + 1), sInvD + D::NU + 16, sT0, lane);     // into a tile-shaped scratch
-        } else if (wave == 2) {
-            tile_inverse<D>(Lb + tile_off<D>(PV + 2, PV + 2), sInvD + D::NU + 32, sT1, lane);
-        } else if (wave == 3) {
+        // round 1: wavefront 3 forms max |s| (the inverses of the diagonal blocks came with the factor, see cholesky_wave)
+        if (wave == 3) {
+            if (lane < D::NV) sSvec[lane] = (sSv[4 * lane] + sSv[4 * lane + 1]) + (sSv[4 * lane + 2] + sSv[4 * lane + 3]);
             double gm = 0.0;
             for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
             if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
@@ -2478,6 +2486,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     };
     init_corner_rhs();
     if (tid < D::NP) sZ[tid] = (hold && tid >= D::NZ - 4 && tid < D::NZ) ? sVprev[tid - (D::NZ - 4)] : 0.0;
+    if constexpr (S::DUAL3) {   // (see cholesky_wave: the box QP finds the corner inverses ready; wavefront 0 is about to sweep)
+        if (wave == 1)
+            tile_inverse<D>(Lb + tile_off_c<D>(PV + 2, PV + 2), sInvD + D::NU + 32, smem + S::oDual3T1, lane);
+    }
     __syncthreads();
 
     // one tile step of the sweep over the corner; `prescribed` = throttles already fixed in sZ
