@@ -588,6 +588,24 @@ VS_DEV void tile_inverse(const double* __restrict__ Lpp, const double* __restric
     }
 }
 
+// rows I0 .. I1 - 1 of tile_inverse, resumable: x carries the column of this lane between calls (rows < I0 done before)
+template <int I0, int I1>
+VS_DEV void tile_inverse_rows(const double* __restrict__ Lpp, const double* __restrict__ invd, double (&x)[16], int lane) {
+    const int j = lane & 15;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < i; k += 2) {
+            s0 = fma(Lpp[i * 17 + k], x[k], s0);
+            s1 = fma(Lpp[i * 17 + k + 1], x[k + 1], s1);
+        }
+        if (i & 1) s0 = fma(Lpp[i * 17 + i - 1], x[i - 1], s0);
+        const double di = invd[i];
+        x[i] = (i == j) ? di : -di * (s0 + s1);
+    }
+}
+
 // Compile-time work lists of wavefront W: for every panel p the slots whose tile lies right of the panel column
 // (trailing update), and for every tile row r the slots whose tile (r, q), q < min(r, PVT), is kept in registers
 // after P3 (back-substitution).
@@ -2486,10 +2504,6 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     };
     init_corner_rhs();
     if (tid < D::NP) sZ[tid] = (hold && tid >= D::NZ - 4 && tid < D::NZ) ? sVprev[tid - (D::NZ - 4)] : 0.0;
-    if constexpr (S::DUAL3) {   // (see cholesky_wave: the box QP finds the corner inverses ready; wavefront 0 is about to sweep)
-        if (wave == 1)
-            tile_inverse<D>(Lb + tile_off_c<D>(PV + 2, PV + 2), sInvD + D::NU + 32, smem + S::oDual3T1, lane);
-    }
     __syncthreads();
 
     // one tile step of the sweep over the corner; `prescribed` = throttles already fixed in sZ
@@ -2577,6 +2591,53 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             if (lane < 16) { sZ[gj] = z; sZ[16 * PV + j] = z6; }
         }
         __syncthreads();
+    } else if constexpr (S::DUAL3) {
+        // three throttle tile rows.  Wavefront 1 forms the inverse of the last corner diagonal tile for the box QP beside
+        // wavefront 0's sweep (see cholesky_wave for the second one), a few rows in front of every step so that no barrier
+        // of the sweep waits for it
+        static_assert(D::NT - 1 == PV + 2, "three throttle tile rows");
+        double x2[16];
+        const double* L22d = Lb + tile_off_c<D>(PV + 2, PV + 2);
+        const double* inv2 = sInvD + D::NU + 32;
+        if (wave == 1) tile_inverse_rows<0, 8>(L22d, inv2, x2, lane);
+        sweep_tile(PV + 2, false);
+        // the other two tile rows have no pinned or prescribed entry in this pass and their inverses are at hand (X_PVT from
+        // P3, the second one from P3's last panel): z = X^T w, sixteen multiply-adds per lane instead of a 16-step
+        // broadcast chain
+        auto sweep_tile_x = [&](int p, const double* Xp) {
+            if (wave == 0) {
+                const int j = lane & 15;
+                double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {   // X[k][j] = 0 for k < j (stored zeros); w: uniform addresses
+                    z0 = fma(Xp[k * 17 + j], sW[16 * p + k], z0);
+                    z1 = fma(Xp[(k + 1) * 17 + j], sW[16 * p + k + 1], z1);
+                }
+                if (lane < 16) sZ[16 * p + j] = z0 + z1;
+            }
+            __syncthreads();
+            if (p > PV) {
+                if (tid >= 16 * PV && tid < 16 * p) {
+                    const double* T = Lb + tile_off<D>(p, tid >> 4) + (tid & 15);
+                    const double* zp = sZ + 16 * p;
+                    double a2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a2 += T[k * 17] * zp[k];
+                    sW[tid] -= a2;
+                }
+                __syncthreads();
+            }
+        };
+        if (wave == 1) tile_inverse_rows<8, 13>(L22d, inv2, x2, lane);
+        sweep_tile_x(PV + 1, smem + S::oDual3T0);
+        if (wave == 1) {
+            tile_inverse_rows<13, 16>(L22d, inv2, x2, lane);
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) smem[S::oDual3T1 + i * 17 + lane] = x2[i];
+            }
+        }
+        sweep_tile_x(PV, sXinv + PV * D::TS);
     } else {
 #pragma unroll 1
         for (int p = D::NT - 1; p >= PV; --p) sweep_tile(p, false);
