@@ -862,10 +862,13 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
                     double part = acc[q][0] * zz[0];
 #pragma unroll
                     for (int i = 1; i < 4; ++i) part = fma(acc[q][i], zz[i], part);
-                    up[tab.tj[t]] += row_sum4(part);
+                    up[tab.tj[t]] += part;   // per 16-lane row; the four rows are summed once, when the column is published
                 }
             }
-            if (r - 1 < PVT && lane < 16) myU[16 * (r - 1) + j] = up[r - 1];
+            if (r - 1 < PVT) {
+                const double usum = row_sum4(up[r - 1]);
+                if (lane < 16) myU[16 * (r - 1) + j] = usum;
+            }
             __syncthreads();
         }
     }
