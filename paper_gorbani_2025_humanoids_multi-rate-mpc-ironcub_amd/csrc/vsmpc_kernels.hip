@@ -372,17 +372,14 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
 //     the wave's stream blocks at every MFMA issue until the pipe is free (64 cycles), an LDS read returns in ~130.
 //     `ha`/`hb` carry the first SYRK_DIST operand pairs of the slot in and those of the NEXT slot (slot q - 1) out.
 // Build-time switches (measurement variants, tools/exp_build.sh): VS_SYRK_DIST prefetch distance, VS_SYRK_TIED inline
-// assembly with a tied accumulator, VS_LAT_FORM 1 | 2 the latency form (2 = four wavefronts, recursion and SYRK in one
-// stream), VS_SYRK_UNROLL / VS_UNROLL_TPW unrolled passes up to that many slots per wavefront.
+// assembly with a tied accumulator, VS_SYRK_UNROLL / VS_UNROLL_TPW unrolled passes up to that many slots per wavefront,
+// VS_DUAL3_MAX / VS_KMID the box QP's dual-form threshold and register-solver size at long horizons.
 // ------------------------------------------------------------------------------------------------
 #ifndef VS_SYRK_DIST
 #define VS_SYRK_DIST 2
 #endif
 #ifndef VS_SYRK_TIED
 #define VS_SYRK_TIED 0
-#endif
-#ifndef VS_LAT_FORM
-#define VS_LAT_FORM 1
 #endif
 #ifndef VS_UNROLL_TPW
 #define VS_UNROLL_TPW 12
