@@ -2700,118 +2700,131 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         sF[e] = f;
     }
     __syncthreads();
-    if (wave == 0) {
-        // The model is a cascade (systemDynamicsVSMPC.cpp:79-103,288-319,384-429): jets -> momenta -> CoM / RPY ->
-        // error integrators.  Each link is a short register recursion in a few lanes of ONE wavefront; links hand
-        // their trajectories over through sX (LDS operations of a wavefront execute in order).
-        // Every chain first pulls a chunk of CHK stages of its forcing terms into registers (the loads cannot be
-        // hoisted past the trajectory stores by the compiler), then runs the recursion on registers.
-        constexpr int CHK = D::N <= 20 ? D::N : 9;  // short horizons: the whole horizon in one register chunk
-        // (1) jets: lane i < 4 carries (T_i, Tdot_i)
-        if (lane < NTH) {
-            const int i = lane;
-            const double jon = sA[(12 + i) * NX + 16 + i], ja = sA[(16 + i) * NX + 12 + i], jb = sA[(16 + i) * NX + 16 + i];
-            double T = sIn[VSMPC_IN_X0 + 12 + i], Td = sIn[VSMPC_IN_X0 + 16 + i];
-            sX[12 + i] = T;
-            sX[16 + i] = Td;
-#pragma unroll 1
-            for (int k0 = 0; k0 < D::N; k0 += CHK) {
-                double fa[CHK], fb[CHK], dtk[CHK];
-#pragma unroll
-                for (int u = 0; u < CHK; ++u) {
-                    const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
-                    fa[u] = sF[NX * k + 12 + i];
-                    fb[u] = sF[NX * k + 16 + i];
-                    dtk[u] = sDt[k];
-                }
-#pragma unroll
-                for (int u = 0; u < CHK; ++u) {
-                    const double dT = fma(jon, Td, fa[u]);
-                    const double dTd = fma(ja, T, fma(jb, Td, fb[u]));
-                    T = fma(dtk[u], dT, T);
-                    Td = fma(dtk[u], dTd, Td);
-                    if (k0 + u < D::N) {
-                        sX[NX * (k0 + u + 1) + 12 + i] = T;
-                        sX[NX * (k0 + u + 1) + 16 + i] = Td;
-                    }
-                }
-            }
+    {
+        // The three links of the cascade (jets -> momenta -> CoM / RPY + error integrators; systemDynamicsVSMPC.cpp:
+        // 79-103,288-319,384-429) run in THREE wavefronts, one chunk of CHK stages apart: step s = jets of chunk s (wavefront
+        // 0), momenta of chunk s - 1 (wavefront 1, after adding A_mom T_k to its forcing), CoM / RPY of chunk s - 2
+        // (wavefront 2); a workgroup barrier per step hands the trajectories over through sX.  NCH + 2 steps instead of the
+        // 3 NCH chunk-lengths one wavefront needs for the links in series (through v19: 8.1 k cycles at the paper horizon,
+        // 17.0 k at the 2x horizon; now 7.1 k / 11.6 k).
+        constexpr int CHK = D::N > 20 ? 9 : 6, NCH = (D::N + CHK - 1) / CHK;
+        // chain states (registers of the owning lanes, alive across the steps)
+        double jT = 0.0, jTd = 0.0, jon = 0.0, ja = 0.0, jb = 0.0;
+        double Sk[9], hh[3] = {0.0, 0.0, 0.0};
+        double cm0 = 0.0, cm1 = 0.0, cm2 = 0.0, cce = 0.0, cx = 0.0, cee = 0.0;
+        const int hr0m = (lane & 1) ? 9 : 3;                       // wavefront 1, lane < 2: h_lin / h_ang
+        const int cg = lane / 3, cr = lane - 3 * cg;               // wavefront 2, lane < 6: (half, row)
+        const int cxr = (cg ? 6 : 0) + cr, chr0 = cg ? 9 : 3, cer = (cg ? 23 : 20) + cr;
+        if (wave == 0 && lane < NTH) {
+            jon = sA[(12 + lane) * NX + 16 + lane]; ja = sA[(16 + lane) * NX + 12 + lane]; jb = sA[(16 + lane) * NX + 16 + lane];
+            jT = sIn[VSMPC_IN_X0 + 12 + lane]; jTd = sIn[VSMPC_IN_X0 + 16 + lane];
+            sX[12 + lane] = jT;
+            sX[16 + lane] = jTd;
         }
-        // (2) momentum forcing g_k = A_mom T_k + f_k on the six momentum rows, all stages at once (into sF)
-        for (int e = lane; e < 6 * D::N; e += 64) {
-            const int k = e / 6, rr = e - 6 * k, row = rr < 3 ? 3 + rr : 6 + rr;  // rows 3..5, 9..11
-            double gk = sF[NX * k + row];
-#pragma unroll
-            for (int c = 0; c < NTH; ++c) gk = fma(sA[row * NX + 12 + c], sX[NX * k + 12 + c], gk);
-            sF[NX * k + row] = gk;
-        }
-        // (3) momenta: lane g < 2 carries h_lin (g = 0) or h_ang (g = 1), h' = -S(omega) h + g_k
-        if (lane < 2) {
-            const int hr0 = lane ? 9 : 3;
-            double Sk[9], h[3];
+        if (wave == 1 && lane < 2) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                h[r] = sIn[VSMPC_IN_X0 + hr0 + r];
-                sX[hr0 + r] = h[r];
+                hh[r] = sIn[VSMPC_IN_X0 + hr0m + r];
+                sX[hr0m + r] = hh[r];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Sk[3 * r + c] = sA[(hr0 + r) * NX + hr0 + c];
+                for (int c = 0; c < 3; ++c) Sk[3 * r + c] = sA[(hr0m + r) * NX + hr0m + c];
             }
-#pragma unroll 1
-            for (int k0 = 0; k0 < D::N; k0 += CHK) {
-                double gk[CHK][3], dtk[CHK];
+        }
+        if (wave == 2 && lane < 6) {
+            cm0 = sA[cxr * NX + chr0]; cm1 = sA[cxr * NX + chr0 + 1]; cm2 = sA[cxr * NX + chr0 + 2];
+            cce = sC[cer];
+            cx = sIn[VSMPC_IN_X0 + cxr]; cee = sIn[VSMPC_IN_X0 + cer];
+            sX[cxr] = cx;
+            sX[cer] = cee;
+        }
+        static_for<0, NCH + 2>([&](auto scst) __attribute__((always_inline)) {
+            constexpr int st = decltype(scst)::value;
+            if constexpr (st < NCH) {   // jets, chunk st
+                if (wave == 0 && lane < NTH) {
+                    constexpr int k0 = st * CHK;
+                    double fa[CHK], fb[CHK], dtk[CHK];
 #pragma unroll
-                for (int u = 0; u < CHK; ++u) {
-                    const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+                    for (int u = 0; u < CHK; ++u) {
+                        const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+                        fa[u] = sF[NX * k + 12 + lane];
+                        fb[u] = sF[NX * k + 16 + lane];
+                        dtk[u] = sDt[k];
+                    }
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) gk[u][r] = sF[NX * k + hr0 + r];
-                    dtk[u] = sDt[k];
-                }
-#pragma unroll
-                for (int u = 0; u < CHK; ++u) {
-                    double dh[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        dh[r] = fma(Sk[3 * r], h[0], fma(Sk[3 * r + 1], h[1], fma(Sk[3 * r + 2], h[2], gk[u][r])));
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) h[r] = fma(dtk[u], dh[r], h[r]);
-                    if (k0 + u < D::N) {
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) sX[NX * (k0 + u + 1) + hr0 + r] = h[r];
+                    for (int u = 0; u < CHK; ++u) {
+                        const double dT = fma(jon, jTd, fa[u]);
+                        const double dTd = fma(ja, jT, fma(jb, jTd, fb[u]));
+                        jT = fma(dtk[u], dT, jT);
+                        jTd = fma(dtk[u], dTd, jTd);
+                        if (k0 + u < D::N) {
+                            sX[NX * (k0 + u + 1) + 12 + lane] = jT;
+                            sX[NX * (k0 + u + 1) + 16 + lane] = jTd;
+                        }
                     }
                 }
             }
-        }
-        // (4) CoM / RPY and their error integrators: lane (g, r) < 6, x' = M1 h, e' = x + c_e
-        if (lane < 6) {
-            const int g = lane / 3, r = lane - 3 * g;
-            const int xr = (g ? 6 : 0) + r, hr0 = g ? 9 : 3, er = (g ? 23 : 20) + r;
-            const double m0 = sA[xr * NX + hr0], m1 = sA[xr * NX + hr0 + 1], m2 = sA[xr * NX + hr0 + 2];
-            const double ce = sC[er];
-            double x = sIn[VSMPC_IN_X0 + xr], ee = sIn[VSMPC_IN_X0 + er];
-            sX[xr] = x;
-            sX[er] = ee;
-#pragma unroll 1
-            for (int k0 = 0; k0 < D::N; k0 += CHK) {
-                double hk[CHK][3], dtk[CHK];
+            if constexpr (st >= 1 && st - 1 < NCH) {   // momenta, chunk st - 1
+                if (wave == 1) {
+                    constexpr int k0 = (st - 1) * CHK;
+                    constexpr int kn = k0 + CHK < D::N ? CHK : D::N - k0;   // stages of this chunk
+                    // forcing g_k = A_mom T_k + f_k on the six momentum rows of the chunk's stages (T_k: the previous step's jets)
+                    if (lane < 6 * kn) {
+                        const int k = k0 + lane / 6, rr = lane % 6, row = rr < 3 ? 3 + rr : 6 + rr;   // rows 3..5, 9..11
+                        double gk = sF[NX * k + row];
 #pragma unroll
-                for (int u = 0; u < CHK; ++u) {
-                    const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+                        for (int c = 0; c < NTH; ++c) gk = fma(sA[row * NX + 12 + c], sX[NX * k + 12 + c], gk);
+                        sF[NX * k + row] = gk;
+                    }
+                    if (lane < 2) {   // (LDS operations of one wavefront execute in order: the forcing above is visible)
+                        double gk[CHK][3], dtk[CHK];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) hk[u][c] = sX[NX * k + hr0 + c];
-                    dtk[u] = sDt[k];
-                }
+                        for (int u = 0; u < CHK; ++u) {
+                            const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
 #pragma unroll
-                for (int u = 0; u < CHK; ++u) {
-                    const double dx = fma(m0, hk[u][0], fma(m1, hk[u][1], m2 * hk[u][2]));
-                    ee = fma(dtk[u], x + ce, ee);
-                    x = fma(dtk[u], dx, x);
-                    if (k0 + u < D::N) {
-                        sX[NX * (k0 + u + 1) + xr] = x;
-                        sX[NX * (k0 + u + 1) + er] = ee;
+                            for (int r = 0; r < 3; ++r) gk[u][r] = sF[NX * k + hr0m + r];
+                            dtk[u] = sDt[k];
+                        }
+#pragma unroll
+                        for (int u = 0; u < CHK; ++u) {
+                            double dh[3];
+#pragma unroll
+                            for (int r = 0; r < 3; ++r)
+                                dh[r] = fma(Sk[3 * r], hh[0], fma(Sk[3 * r + 1], hh[1], fma(Sk[3 * r + 2], hh[2], gk[u][r])));
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) hh[r] = fma(dtk[u], dh[r], hh[r]);
+                            if (k0 + u < D::N) {
+#pragma unroll
+                                for (int r = 0; r < 3; ++r) sX[NX * (k0 + u + 1) + hr0m + r] = hh[r];
+                            }
+                        }
                     }
                 }
             }
-        }
+            if constexpr (st >= 2 && st - 2 < NCH) {   // CoM / RPY and their error integrators, chunk st - 2
+                if (wave == 2 && lane < 6) {
+                    constexpr int k0 = (st - 2) * CHK;
+                    double hk[CHK][3], dtk[CHK];
+#pragma unroll
+                    for (int u = 0; u < CHK; ++u) {
+                        const int k = (k0 + u < D::N) ? k0 + u : D::N - 1;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) hk[u][c] = sX[NX * k + chr0 + c];
+                        dtk[u] = sDt[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CHK; ++u) {
+                        const double dx = fma(cm0, hk[u][0], fma(cm1, hk[u][1], cm2 * hk[u][2]));
+                        cee = fma(dtk[u], cx + cce, cee);
+                        cx = fma(dtk[u], dx, cx);
+                        if (k0 + u < D::N) {
+                            sX[NX * (k0 + u + 1) + cxr] = cx;
+                            sX[NX * (k0 + u + 1) + cer] = cee;
+                        }
+                    }
+                }
+            }
+            if constexpr (st + 1 < NCH + 2) __syncthreads();
+        });
     }
     __syncthreads();
     VS_STAMP(8);
