@@ -963,7 +963,8 @@ template <class D>
 struct XTiles {
     static constexpr int NVS = D::NV + 1, NR2 = D::NV - 16;
     static constexpr int KMAX = SMALL_SOLVE_MAX;   // largest system solved in registers (the accumulator tiles are in VGPRs here)
-    static constexpr int KMID = 0;                 // no mid-size register solver: no registers for it
+    static constexpr int KMID = 16;                // compact row-per-lane solver for 7..16 active bounds (mid_spd_solve): it fits
+                                                   // beside the accumulator tiles without a spilled register
     const double* X6;
     const double* sXr;
     VS_DEV double col(int j, int r, int n) const {
@@ -1208,7 +1209,7 @@ VS_DEV void box_qp(int n_violated, bool hold) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool DUALQP = S::DUALQP;
     constexpr int PV = D::PVT;
-    constexpr int DUAL_MAX_ACTIVE = 10;
+    constexpr int DUAL_MAX_ACTIVE = 16;   // (10 before the register solver for mid-size active sets: take-off batch -1.4 %)
     constexpr bool DUAL3 = S::DUAL3;
 #ifndef VS_DUAL3_MAX
 #define VS_DUAL3_MAX 24
