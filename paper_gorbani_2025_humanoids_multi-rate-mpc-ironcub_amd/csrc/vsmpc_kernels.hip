@@ -1709,10 +1709,13 @@ VS_DEV void p1s_chain(const DevCfg& cfg, int half, int lane, double* __restrict_
 #pragma unroll
         for (int r = 0; r < 6; ++r) rf[r] = rf_n[r];
         if constexpr (KIND == 1) {
-            if (m >= 2) {
+            // reference column of node m - 1; the window only moves at the slow rate, so the fast nodes share column 0
+            // and need no reload (costsVSMPC.cpp:191-200)
+            const int rc = m - 2 < D::NS ? 0 : m - 2 - D::NS;
+            const int rc_cur = m - 1 < D::NS ? 0 : m - 1 - D::NS;
+            if (m >= 2 && rc != rc_cur) {
                 int zo = 0;
                 asm volatile("" : "+v"(zo));
-                const int rc = m - 2 < D::NS ? 0 : m - 2 - D::NS;   // reference column of node m - 1
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     rf_n[r] = refRow[rc * 12 + yx0 + r + zo];
