@@ -1284,7 +1284,7 @@ VS_DEV void box_qp(int n_violated, bool hold) {
        if constexpr (DUAL3) {
         // ---- dual form, three throttle tile rows: X = L22^-1 assembled dense in LDS from tile products,
         //   X_ii = L_ii^-1 (the first one from P3, the other two here),  X10 = -X1 (L10 X0),  X21 = -X2 (L21 X1),
-        //   X20 = -X2 (L20 X0 + L21 X10);  one 16x16 entry per thread and product, four barrier-separated rounds.
+        //   X20 = -X2 (L20 X0 + L21 X10)  (one round on the matrix cores, below)
         constexpr int NVS = D::NV + 1, R2 = D::NV - 32;        // throttle rows in the last tile row
         double* sXd = sQP + D::NV * NVS;                        // sXd[j * NVS + i] = X[j][i]
         double* sT0 = smem + S::oDual3T0;                       // X1 on entry (from P3); L10 X0, later L20 X0 + L21 X10
@@ -1294,7 +1294,6 @@ VS_DEV void box_qp(int n_violated, bool hold) {
         const double* L20 = Lb + tile_off<D>(PV + 2, PV);
         const double* L21 = Lb + tile_off<D>(PV + 2, PV + 1);
         const double* X0 = sXinv + PV * D::TS;                  // from P3
-        const int ti = tid >> 4, tj = tid & 15;                 // entry (ti, tj) of a 16 x 16 product
         auto xd = [&](int blk_r, int blk_c) { return sXd + (16 * blk_r) * NVS + 16 * blk_c; };   // block of X, row stride NVS
         for (int e = tid; e < D::NV * NVS; e += D::BLOCK) sXd[e] = 0.0;
         if (tid < 4 * D::NV) {   // s = L22 (L^-1 g)_v (its largest entry scales the release tolerance): four threads per row,
@@ -1305,60 +1304,65 @@ VS_DEV void box_qp(int n_violated, bool hold) {
             sSv[tid] = sum;                           // partial sums: P's array is not in use before round 6
         }
         __syncthreads();
-        // round 1: wavefront 3 forms max |s| (the inverses of the diagonal blocks came with the factor, see cholesky_wave)
-        if (wave == 3) {
-            if (lane < D::NV) sSvec[lane] = (sSv[4 * lane] + sSv[4 * lane + 1]) + (sSv[4 * lane + 2] + sSv[4 * lane + 3]);
-            double gm = 0.0;
-            for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
-            if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
-        }
-        __syncthreads();
-        {   // copy the three diagonal blocks into the dense X (lower triangles; rows of the last block beyond R2 stay zero)
-            const double x0 = X0[ti * 17 + tj], x1 = sT0[ti * 17 + tj], x2 = sT1[ti * 17 + tj];
-            if (tj <= ti) {
-                xd(0, 0)[ti * NVS + tj] = x0;
-                xd(1, 1)[ti * NVS + tj] = x1;
-                if (ti < R2) xd(2, 2)[ti * NVS + tj] = x2;
+        // ONE round for the off-diagonal blocks of X, on the matrix cores, each chain in one wavefront: an accumulator
+        // (lane (g, n), register r = entry [g + 4 r][n]) IS the B operand of the next product (k-step r), so a chain of
+        // products needs no LDS round trip and no barrier.  Wavefront 0: T10 = L10 X0, X10 = -X1 T10, T20 = L20 X0 + L21 X10,
+        // X20 = -X2 T20; wavefront 1: T21 = L21 X1, X21 = -X2 T21; wavefront 2 copies the diagonal blocks; wavefront 3 forms
+        // max |s|.  (Through v22: five barrier-separated rounds of 16-term dot products, one entry per thread: the set-up
+        // of the box QP cost 14.5 k cycles.)  X2 is R2 x R2: its rows and columns beyond R2 do not exist (masked operands).
+        {
+            const int g = lane >> 4, n = lane & 15;
+            auto a_tile = [&](const double* T, int ks) { return T[n * 17 + 4 * ks + g]; };         // A[m = n][k]
+            auto b_tile = [&](const double* T, int ks) { return T[(4 * ks + g) * 17 + n]; };       // B[k][n]
+            auto a_x2 = [&](int ks) {                                                              // X2 restricted to R2 x R2
+                const double v = sT1[n * 17 + 4 * ks + g];
+                return (n < R2 && 4 * ks + g < R2) ? v : 0.0;
+            };
+            const d4 zero = d4{0.0, 0.0, 0.0, 0.0};
+            if (wave == 0) {
+                d4 t10 = zero, x10 = zero, t20 = zero, x20 = zero;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) t10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_tile(L10, ks), b_tile(X0, ks), t10, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) t20 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_tile(L20, ks), b_tile(X0, ks), t20, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_tile(sT0, ks), t10[ks], x10, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x10[r] = -x10[r]; xd(1, 0)[(g + 4 * r) * NVS + n] = x10[r]; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) t20 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_tile(L21, ks), x10[ks], t20, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x20 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_x2(ks), t20[ks], x20, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (g + 4 * r < R2) xd(2, 0)[(g + 4 * r) * NVS + n] = -x20[r];
+            } else if (wave == 1) {
+                d4 t21 = zero, x21 = zero;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) t21 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_tile(L21, ks), b_tile(sT0, ks), t21, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x21 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_x2(ks), t21[ks], x21, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (g + 4 * r < R2) xd(2, 1)[(g + 4 * r) * NVS + n] = -x21[r];
+            } else if (wave == 2) {
+                // the three diagonal blocks into the dense X (lower triangles; rows of the last block beyond R2 stay zero)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = g + 4 * r;
+                    const double x0 = X0[i * 17 + n], x1 = sT0[i * 17 + n], x2 = sT1[i * 17 + n];
+                    if (n <= i) {
+                        xd(0, 0)[i * NVS + n] = x0;
+                        xd(1, 1)[i * NVS + n] = x1;
+                        if (i < R2) xd(2, 2)[i * NVS + n] = x2;
+                    }
+                }
+            } else {
+                if (lane < D::NV) sSvec[lane] = (sSv[4 * lane] + sSv[4 * lane + 1]) + (sSv[4 * lane + 2] + sSv[4 * lane + 3]);
+                double gm = 0.0;
+                for (int c = 0; c < D::NV; ++c) gm = fmax(gm, fabs(sSvec[c]));  // uniform addresses: LDS broadcasts
+                if (lane == 0) sSvec[0] = gm;   // every lane of this wavefront has read sSvec[0] (in-order LDS)
             }
-        }
-        __syncthreads();
-        {   // round 2: T10 = L10 X0, T21 = L21 X1
-            double a = 0.0, b = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                a = fma(L10[ti * 17 + k], xd(0, 0)[k * NVS + tj], a);
-                b = fma(L21[ti * 17 + k], xd(1, 1)[k * NVS + tj], b);
-            }
-            sT0[ti * 16 + tj] = a;
-            sT1[ti * 16 + tj] = b;
-        }
-        __syncthreads();
-        {   // round 3: X10 = -X1 T10, X21 = -X2 T21
-            double a = 0.0, b = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a = fma(xd(1, 1)[ti * NVS + k], sT0[k * 16 + tj], a);
-            const int t2 = ti < R2 ? ti : 0;                    // X2 is R2 x R2: rows / columns beyond it do not exist
-#pragma unroll
-            for (int k = 0; k < R2; ++k) b = fma(xd(2, 2)[t2 * NVS + k], sT1[k * 16 + tj], b);
-            xd(1, 0)[ti * NVS + tj] = -a;
-            if (ti < R2) xd(2, 1)[ti * NVS + tj] = -b;
-        }
-        __syncthreads();
-        {   // round 4: T20 = L20 X0 + L21 X10
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                a = fma(L20[ti * 17 + k], xd(0, 0)[k * NVS + tj], a);
-                a = fma(L21[ti * 17 + k], xd(1, 0)[k * NVS + tj], a);
-            }
-            sT0[ti * 16 + tj] = a;
-        }
-        __syncthreads();
-        {   // round 5: X20 = -X2 T20
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < R2; ++k) a = fma(xd(2, 2)[(ti < R2 ? ti : 0) * NVS + k], sT0[k * 16 + tj], a);
-            if (ti < R2) xd(2, 0)[ti * NVS + tj] = -a;
         }
         __syncthreads();
         {   // round 6: ALL of P = X_N^T X_N on the matrix cores (six lower 16 x 16 tiles, twelve k-steps each, over the four
