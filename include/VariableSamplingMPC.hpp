@@ -17,7 +17,19 @@
 //   VariableSamplingMPCT<...>   the reference's surface -- configure(parametersHandler, qpInput) / update(qpInput) /
 //                               solveMPC() / get*Reference(out) (variableSamplingMPC.h:15-41, IMPCProblem.h:35-148,
 //                               MPCPyBindings.cpp:22-90) -- over TickMachine + the C-ABI.  The class a maintainer adds
-//                               to the reference is an instantiation of it.
+//                               to the reference is VariableSamplingMPCT<QPInput, TrajectoryManager> (INTEGRATION.md
+//                               section 2).  What that instantiation meets inside the reference, and what this header
+//                               therefore does NOT assume:
+//                                 * QPInput's setters take Eigen::Ref<const Eigen::Vector3d> / const Eigen::Vector6d&
+//                                   (QPInput.h:41,45,67): nothing converts to those from a double*.  Arguments are
+//                                   built by fixedArg<N>() -- an Eigen::Map when <Eigen/Core> can be included, a small
+//                                   view with operator()/data() otherwise;
+//                                 * TrajectoryManager::getCurrentValue returns an Eigen::VectorXd BY VALUE
+//                                   (TrajectoryManager.h:104) and there is no has(): values are kept alive in a local
+//                                   and read with [], optional tracks are probed only where the type offers has();
+//                                 * configure receives a std::weak_ptr<IParametersHandler> (IMPCProblem.h:35).
+//                               tests/cpp/reference_surface_driver.cpp builds exactly this instantiation against
+//                               signature-exact stand-ins of those headers (tests/cpp/refstub/).
 //   VariableSamplingMPC         record-level front end (update(record)): the caller already holds the vsmpc_input record.
 //
 // All numerics run in libvsmpc.so (HIP): Lambda_lin / Lambda_ang / I_G through vsmpc_kinematics_batch, update()+solveMPC()
@@ -31,11 +43,56 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "vsmpc.h"
 
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define VSMPC_HOST_HAS_EIGEN 1
+#endif
+#endif
+
 namespace vsmpc_host {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fixedArg<N>(p): the argument handed to a QPInput setter for N doubles at p.  Inside the reference (Eigen present) an
+// Eigen::Map<const Matrix<double, N, 1>>: converts implicitly to Eigen::Ref<const Vector3d> (QPInput.h:41,45) and to a
+// const Vector6d& temporary (QPInput.h:67).  Without Eigen (this repo's own front ends) a view with the same read access.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int N>
+struct FixedView {
+    const double* p;
+    double operator()(int i) const { return p[i]; }
+    double operator[](int i) const { return p[i]; }
+    const double* data() const { return p; }
+    int size() const { return N; }
+};
+#ifdef VSMPC_HOST_HAS_EIGEN
+template <int N>
+inline Eigen::Map<const Eigen::Matrix<double, N, 1>> fixedArg(const double* p) {
+    return Eigen::Map<const Eigen::Matrix<double, N, 1>>(p);
+}
+#else
+template <int N>
+inline FixedView<N> fixedArg(const double* p) { return FixedView<N>{p}; }
+#endif
+
+// hasTrack(traj, name): TrajT::has(name) where the type has one (vsmpc_host::Trajectory); the reference's
+// TrajectoryManager has none and loads every variable of its MAT file, RPY and RPYDot included (TrajectoryManager.cpp:
+// 95-127; a missing key throws from map::at, :160-167) -- there every track the reference reads is taken as present.
+template <class T, class = void>
+struct HasTrackProbe : std::false_type {};
+template <class T>
+struct HasTrackProbe<T, std::void_t<decltype(std::declval<const T&>().has(std::declval<const std::string&>()))>> : std::true_type {};
+template <class T>
+inline bool hasTrack(const T& traj, const std::string& name) {
+    if constexpr (HasTrackProbe<T>::value) return traj.has(name);
+    else return true;
+}
 
 constexpr int kRobotJoints = VSMPC_KIN_NJ;   // MPCPyBindings.cpp:43 hard-codes 23 joints; the kinematics record does too
 constexpr int kJets = VSMPC_N_THRUSTS;
@@ -334,9 +391,19 @@ public:
         m_thrustDot.assign(4, 0.0);
         m_throttle.assign(4, 0.0);
         m_finalState.assign(VSMPC_N_STATES, 0.0);
+        m_x.assign(m_nVar, 0.0);          // per-tick scratch: allocated here, never in assemble() / solve()
+        m_kin.assign(VSMPC_KIN_SIZE, 0.0);
+        m_kinPending = false;
         m_status = 0;
         return assemble(robot, ref, qp, wb);   // IMPCProblem.cpp:80-132 evaluates every plugin once
     }
+
+    // Fused tick (default): assemble() only PACKS -- the raw Robot quantities of the Lambda / I_G terms go into the
+    // kinematics record -- and solve() submits kinematics -> solve in one vsmpc_tick call (one synchronisation per tick).
+    // Off: assemble() completes the record itself (vsmpc_kinematics_batch) and solve() is vsmpc_solve_batch: two round
+    // trips, but record() is complete between update() and solveMPC().
+    void setFusedTick(bool fused) { m_fused = fused; }
+    bool fusedTick() const { return m_fused; }
 
     // One IMPCProblem::update worth of plugin evaluations, in the reference's order -- costs (reference tracking,
     // regularisation, throttle anchor, joint posture), then constraints (dynamics: angular, linear, jets; initial state;
@@ -374,17 +441,21 @@ public:
         rec[VSMPC_IN_MASS] = double(float(ref.totalMass));                             // Robot.h:338 keeps a float
         std::memcpy(rec + VSMPC_IN_WRB, R, sizeof(double) * 9);
         mulRt(R, robot.baseAngVel, rec + VSMPC_IN_OMEGA);
-        const double alpha = m_alpha->getCurrentValue("alphaGravity")[0];              // systemDynamicsVSMPC.cpp:308-311
+        double alpha;
+        {
+            const auto a = m_alpha->getCurrentValue(std::string("alphaGravity"));      // systemDynamicsVSMPC.cpp:308-311
+            alpha = a[0];
+        }
         wb.alphaGravity = alpha;
         m_alpha->advanceTrajectory();
         rec[VSMPC_IN_ALPHA] = alpha;
         std::memcpy(rec + VSMPC_IN_GRAV, ref.gravity, sizeof(double) * 3);
         std::memcpy(rec + VSMPC_IN_AMOM, ref.amomBody, sizeof(double) * 24);
-        {
-            std::vector<double> kin(VSMPC_KIN_SIZE, 0.0);
+        kinematicsRecord(robot, ref, m_kin.data());
+        m_kinPending = m_fused;
+        if (!m_fused) {
             double out[VSMPC_KIN_OUT];
-            kinematicsRecord(robot, ref, kin.data());
-            const int rc = vsmpc_kinematics_batch(m_h, kin.data(), 1, out, nullptr);
+            const int rc = vsmpc_kinematics_batch(m_h, m_kin.data(), 1, out, nullptr);
             if (rc != VSMPC_OK) return rc;
             std::memcpy(rec + VSMPC_IN_LLIN, out, sizeof(double) * 24);
             std::memcpy(rec + VSMPC_IN_LANG, out + 24, sizeof(double) * 24);
@@ -430,12 +501,15 @@ public:
 
     // VariableSamplingMPC::solveMPC (variableSamplingMPC.cpp:88-112) on the record of the last assemble() / setRecord()
     int solve() {
-        std::vector<double> x(m_nVar), fm(VSMPC_FM_SIZE);
+        double fm[VSMPC_FM_SIZE];
+        std::vector<double>& x = m_x;
         int status = 0;
-        const int rc = vsmpc_solve_batch(m_h, m_record.data(), 1, x.data(), fm.data(), &status, nullptr, nullptr);
+        const int rc = m_kinPending ? vsmpc_tick(m_h, m_kin.data(), m_record.data(), 1, x.data(), fm, &status, nullptr, nullptr)
+                                    : vsmpc_solve_batch(m_h, m_record.data(), 1, x.data(), fm, &status, nullptr, nullptr);
+        m_kinPending = false;
         m_status = (rc == VSMPC_OK) ? status : VSMPC_STATUS_NUMERICAL;
         if (m_status == VSMPC_STATUS_SOLVED) {                                         // :91: consume only if Solved
-            m_QPSolution = x;
+            m_QPSolution.swap(x);                                                      // (both stay m_nVar long)
             for (int i = 0; i < VSMPC_N_JOINTS; ++i) m_deltaJoints[i] = fm[VSMPC_FM_DQ + i];
             for (int i = 0; i < 4; ++i) {
                 m_throttle[i] = fm[VSMPC_FM_THROTTLE + i];
@@ -443,7 +517,7 @@ public:
                 m_thrustDot[i] = fm[VSMPC_FM_THRUSTDOT + i];
             }
             const int N = m_p.cfg.n_iter;
-            for (int i = 0; i < VSMPC_N_STATES; ++i) m_finalState[i] = x[size_t(VSMPC_N_STATES) * N + i];
+            for (int i = 0; i < VSMPC_N_STATES; ++i) m_finalState[i] = m_QPSolution[size_t(VSMPC_N_STATES) * N + i];
             for (int i = 0; i < VSMPC_N_JOINTS; ++i) m_jointsPositionReference[m_sel[i]] += m_deltaJoints[i];   // :104-108
         }
         return rc;
@@ -470,6 +544,8 @@ public:
         m_thrustDot.assign(4, 0.0);
         m_throttle.assign(4, 0.0);
         m_finalState.assign(VSMPC_N_STATES, 0.0);
+        m_x.assign(m_nVar, 0.0);
+        m_kinPending = false;
         m_status = 0;
     }
     // the two counters of the record-level front end alone (no handle needed)
@@ -479,7 +555,8 @@ public:
         for (int i = 0; i < 3; ++i) { m_rpyOld[i] = rpy0 != nullptr ? rpy0[i] : 0.0; m_nTurns[i] = 0.0; }
     }
     void setRecord(const double* record, bool applyTickState) {
-        m_record.assign(record, record + m_nIn);
+        m_record.assign(record, record + m_nIn);   // (same size as before: no reallocation)
+        m_kinPending = false;
         if (!applyTickState) return;
         m_record[VSMPC_IN_HOLD] = nextHoldFlag() ? 1.0 : 0.0;
         double un[3];
@@ -522,19 +599,28 @@ public:
 private:
     // one window column from the CURRENT trajectory sample, getRobot()'s attitude and mass (costsVSMPC.cpp:105-112,127-146)
     int referenceColumn(const RobotView& robot, double col[12]) {
-        const double* p = m_pos->getCurrentValue("positionCoM");
-        const double* v = m_pos->getCurrentValue("velocityCoM");
+        // getCurrentValue may return a pointer (Trajectory) or an Eigen::VectorXd BY VALUE (the reference's
+        // TrajectoryManager, TrajectoryManager.h:104): keep what it returns alive, read with []
+        const auto p = m_pos->getCurrentValue(std::string("positionCoM"));
+        const auto v = m_pos->getCurrentValue(std::string("velocityCoM"));
         double mv[3];
         for (int i = 0; i < 3; ++i) { col[i] = m_initialCoMPos[i] + p[i]; mv[i] = robot.totalMass * v[i]; }
         mulRt(robot.baseRot, mv, col + 3);
         double rpyTrack[3] = {0, 0, 0}, rpyDot[3] = {0, 0, 0};
-        if (m_pos->has("RPY")) std::memcpy(rpyTrack, m_pos->getCurrentValue("RPY"), sizeof(rpyTrack));
-        if (m_pos->has("RPYDot")) std::memcpy(rpyDot, m_pos->getCurrentValue("RPYDot"), sizeof(rpyDot));
+        if (hasTrack(*m_pos, "RPY")) {
+            const auto t = m_pos->getCurrentValue(std::string("RPY"));
+            for (int i = 0; i < 3; ++i) rpyTrack[i] = t[i];
+        }
+        if (hasTrack(*m_pos, "RPYDot")) {
+            const auto t = m_pos->getCurrentValue(std::string("RPYDot"));
+            for (int i = 0; i < 3; ++i) rpyDot[i] = t[i];
+        }
         for (int i = 0; i < 3; ++i) { col[6 + i] = m_initialRPY[i] + rpyTrack[i]; col[9 + i] = 0.0; }
         if (rpyDot[0] != 0.0 || rpyDot[1] != 0.0 || rpyDot[2] != 0.0) {
             // m_inertia * m_W * RPYDot with getRobot()'s locked inertia (costsVSMPC.cpp:111-112,143-146,266-286); I_G on the
             // device, from a kinematics record that carries only the quantities I_G needs
-            std::vector<double> kin(VSMPC_KIN_SIZE, 0.0);
+            std::vector<double>& kin = m_kin;          // (rewritten in full by kinematicsRecord() later in this tick)
+            std::fill(kin.begin(), kin.end(), 0.0);
             double out[VSMPC_KIN_OUT];
             std::memcpy(&kin[VSMPC_KIN_WRB], robot.baseRot, sizeof(double) * 9);
             std::memcpy(&kin[VSMPC_KIN_MB], robot.massMatrixBase, sizeof(double) * 36);
@@ -557,6 +643,7 @@ private:
     // raw Robot quantities in the VSMPC_KIN_* layout (systemDynamicsVSMPC.cpp:128-130,159-226,321-350)
     void kinematicsRecord(const RobotView& robot, const RobotView& ref, double* k) const {
         const int nJ = kRobotJoints;
+        std::memset(k, 0, sizeof(double) * VSMPC_KIN_SIZE);
         std::memcpy(k + VSMPC_KIN_WRB, ref.baseRot, sizeof(double) * 9);
         for (int i = 0; i < 4; ++i) k[VSMPC_KIN_THRUST + i] = ref.jetThrusts[i];
         const bool cst = m_p.constantLambda;
@@ -590,6 +677,8 @@ private:
     std::vector<double> m_window, m_record, m_QPSolution, m_jointsPositionReference, m_jointPosReference, m_deltaJoints;
     std::vector<double> m_thrust, m_thrustDot, m_throttle, m_finalState;
     std::vector<double> m_relJacInit, m_axesInit, m_armsInit;
+    std::vector<double> m_x, m_kin;     // per-tick scratch (solution before it is consumed; kinematics record)
+    bool m_fused = true, m_kinPending = false;
 };
 using TickMachine = TickMachineT<Trajectory>;
 
@@ -625,7 +714,22 @@ public:
 
     void setTrajectories(std::shared_ptr<TrajT> position, std::shared_ptr<TrajT> alpha) { m_pos = position; m_alpha = alpha; }
     void setDevice(int device) { m_device = device; }
+    // one submission per tick (default) or the two-call form whose record is complete right after update(); before configure
+    void setFusedTick(bool fused) { m_fused = fused; }
 
+    // IMPCProblem::configure takes std::weak_ptr<IParametersHandler> (IMPCProblem.h:35; MPCPyBindings.cpp:24-32 makes
+    // one from the shared_ptr Python holds): both spellings, then the handler itself
+    template <class HandlerT>
+    bool configure(std::weak_ptr<HandlerT> parametersHandler, QPInputT& qpInput) {
+        auto ptr = parametersHandler.lock();
+        if (!ptr) { m_message = "parameters handler expired"; return false; }
+        return configure(*ptr, qpInput);
+    }
+    template <class HandlerT>
+    bool configure(std::shared_ptr<HandlerT> parametersHandler, QPInputT& qpInput) {
+        if (!parametersHandler) { m_message = "parameters handler is null"; return false; }
+        return configure(*parametersHandler, qpInput);
+    }
     template <class ParamsT>
     bool configure(ParamsT& parametersHandler, QPInputT& qpInput) {
         MPCParameters p;
@@ -644,6 +748,7 @@ public:
         readRobot(*qpInput.getRobot(), robot, false, true);
         readRobot(*qpInput.getRobotReference(), ref, true);
         readQPInput(qpInput, robot.nJoints, qv);
+        m_tick.setFusedTick(m_fused);
         m_lastError = m_tick.configure(p, m_h, robot, ref, qv, m_pos, m_alpha, wb);
         if (m_lastError != VSMPC_OK) { m_message = vsmpc_strerror(m_lastError); return false; }
         writeBack(qpInput, wb);
@@ -653,9 +758,9 @@ public:
 
     bool update(QPInputT& qpInput) {   // IMPCProblem::update (IMPCProblem.cpp:150-194)
         if (!m_configured) return false;
-        RobotView& robot = m_robot;
+        RobotView& robot = m_robot;      // members: their vectors keep their capacity from tick to tick
         RobotView& ref = m_ref;
-        QPView qv;
+        QPView& qv = m_qv;
         QPWriteBack wb;
         readRobot(*qpInput.getRobot(), robot, false);
         readRobot(*qpInput.getRobotReference(), ref, true);
@@ -696,9 +801,9 @@ public:
 private:
     static void writeBack(QPInputT& qp, const QPWriteBack& wb) {
         if (wb.referencesPushed) {                                                    // costsVSMPC.cpp:155-160
-            qp.setPosCoMReference(wb.posCoMReference);
-            qp.setRPYReference(wb.rpyReference);
-            qp.setMomentumReference(wb.momentumReference);
+            qp.setPosCoMReference(fixedArg<3>(wb.posCoMReference));                   // QPInput.h:41
+            qp.setRPYReference(fixedArg<3>(wb.rpyReference));                         // QPInput.h:45
+            qp.setMomentumReference(fixedArg<6>(wb.momentumReference));               // QPInput.h:67
         }
         qp.setAlphaGravity(wb.alphaGravity);                                          // systemDynamicsVSMPC.cpp:310
     }
@@ -706,8 +811,9 @@ private:
     TickMachineT<TrajT> m_tick;
     std::shared_ptr<TrajT> m_pos, m_alpha;
     RobotView m_robot, m_ref;
+    QPView m_qv;
     int m_device = 0, m_lastError = 0;
-    bool m_configured = false;
+    bool m_configured = false, m_fused = true;
     std::string m_message;
 };
 

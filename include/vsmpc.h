@@ -128,6 +128,7 @@ int vsmpc_input_doubles(const vsmpc_handle* h);    /* n_in  = 162+12(N-nS+1)    
 int vsmpc_max_batch(const vsmpc_handle* h);
 
 /* Replaces update()+solveMPC() for `batch` independent instances (variable_sampling_mpc.py:111-112).
+ * The caller's current HIP device is left as it was found (every entry point of this header does so).
  * Host buffers: in[batch*n_in]; x[batch*nVar] primal in the REFERENCE variable order
  * [X0..XN | U0..U_{H-1} | v0..v_{H-nS}]; first_move[batch*24]; status[batch]; iters[batch] (active-set
  * iterations).  x, first_move, iters may be NULL.  `stream` is a hipStream_t (NULL = default stream);
@@ -167,6 +168,17 @@ int vsmpc_linearize_batch(vsmpc_handle* h, const double* in, int batch, double* 
 #define VSMPC_KIN_SIZE 697
 #define VSMPC_KIN_OUT 57
 int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double* out, double* records);
+
+/* One tick of the reference's surface in ONE submission: update() [the kinematics-derived terms, systemDynamicsVSMPC.cpp:
+ * 128-130,159-226,321-350] + solveMPC() [IMPCProblem.cpp:196-298, variableSamplingMPC.cpp:88-112] as the harness issues
+ * them back to back (src/variable_sampling_mpc.py:111-112).  kin[batch][VSMPC_KIN_SIZE] and in[batch][n_in] are host
+ * buffers; the device writes Lambda_lin,B | Lambda_ang,B | I_G into the records, solves them, and the call returns after
+ * ONE synchronisation with the completed fields copied back into `in` (so `in` is the record that was solved) and the
+ * results in x / first_move / status / iters (x, first_move, iters may be NULL).  batch <= 8 runs through the handle's
+ * pinned, device-mapped staging buffer without any copy engine work: the form a 200 Hz single-robot caller uses
+ * (include/VariableSamplingMPC.hpp, TickMachineT).  No allocation. */
+int vsmpc_tick(vsmpc_handle* h, const double* kin, double* in, int batch, double* x, double* first_move, int* status,
+               int* iters, void* stream);
 
 /* Options of vsmpc_kinematics_batch, per handle.
  *   joint_selector[8] (or NULL = keep): robot joint index of every controlled joint, for the columns of Lambda_ang -- the
@@ -221,6 +233,8 @@ typedef struct {
  * given, the fields update() pulls out of the Robot patched in place: X0 position / momentum / RPY / thrusts, MASS, WRB,
  * OMEGA, GRAV, AMOM, RPY, T0, and -- through the kinematics kernel on the device, no host round trip -- LLIN, LANG,
  * INERTIA.  Everything else of the record (references, throttle feedback, hold flag) stays the caller's. */
+/* With jointsLambdaOption "constant" set on the handle, patching `records` is refused (VSMPC_ERR_UNSUPPORTED_CONFIG): that
+ * option re-reads the Jacobian slots as configure-time quantities the provider does not deliver. */
 int vsmpc_provider_batch(vsmpc_handle* h, const vsmpc_tree* tree, const double* state, int batch, double* kin,
                          double* robot, double* records);
 

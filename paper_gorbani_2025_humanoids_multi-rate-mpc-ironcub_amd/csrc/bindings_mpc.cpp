@@ -10,10 +10,16 @@
 // return objects with the Robot getters of utils/include/Robot.h (arrays come back as numpy).  Both are read through the
 // SAME templates (include/VariableSamplingMPC.hpp: readRobot / readQPInput / readParameters -> TickMachine) that compile
 // against the reference's C++ classes; this file only adapts Python attribute access to those member names.
-// The trajectories the reference reads from MAT files (groups POSITION_TRAJECTORY / TRAJECTORY_MANAGER) are passed as arrays
-// under those group names (positionCoM, velocityCoM, RPY, RPYDot, fps | alphaGravity, fps): MAT reading stays outside.
-// A second, record-level overload -- update(record) after configure(dict, jointPositions, initialRPY) -- serves callers that
-// already hold the vsmpc_input record.  Host-only glue -> libvsmpc.so; no numerics here.
+// The trajectories the reference reads from MAT files (groups POSITION_TRAJECTORY / TRAJECTORY_MANAGER,
+// src/config/vs_mcp_config.xml:34-40: a `trajectoryFile` name each, loaded by TrajectoryManager.cpp:40-140) reach this
+// module either as arrays under those group names (positionCoM, velocityCoM, RPY, RPYDot, fps | alphaGravity, fps) or --
+// the handler exactly as the harness read it from XML -- as the `trajectoryFile` name, which is handed to a LOADER
+// callable (setTrajectoryLoader / the module-level set_trajectory_loader; trajectory_io.load_mat_trajectory is the
+// default the package installs): loader(fileName) -> mapping {variable: array, "fps": int}.  MAT decoding itself stays
+// in Python.
+// A second, record-level entry -- update(record) after configureRecord(dict, jointPositions, initialRPY) -- serves callers
+// that already hold the vsmpc_input record (its own name: `configure` has exactly the reference's signature, so that
+// configure(handler, mpcInput, device) with a dict handler cannot be mis-dispatched).  Host-only glue -> libvsmpc.so; no numerics here.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -127,9 +133,10 @@ public:
     PyVec getOutputQPJointsPosition() const { return PyVec(m.attr("getOutputQPJointsPosition")()); }
     PyVec getPosCoMReference() const { return PyVec(m.attr("getPosCoMReference")()); }
     PyVec getRPYReference() const { return PyVec(m.attr("getRPYReference")()); }
-    void setPosCoMReference(const double* v) { set("setPosCoMReference", v, 3); }
-    void setRPYReference(const double* v) { set("setRPYReference", v, 3); }
-    void setMomentumReference(const double* v) { set("setMomentumReference", v, 6); }
+    // (vsmpc_host::fixedArg<N> hands over an Eigen::Map when Eigen is installed, a FixedView otherwise: anything with data())
+    template <class V> void setPosCoMReference(const V& v) { set("setPosCoMReference", v.data(), 3); }
+    template <class V> void setRPYReference(const V& v) { set("setRPYReference", v.data(), 3); }
+    template <class V> void setMomentumReference(const V& v) { set("setMomentumReference", v.data(), 6); }
     void setAlphaGravity(double a) { if (py::hasattr(m, "setAlphaGravity")) m.attr("setAlphaGravity")(a); }
 
 private:
@@ -186,6 +193,22 @@ private:
     }
     py::object m;
 };
+
+py::object& default_loader() { static py::object* l = new py::object(py::none()); return *l; }
+
+// a trajectory group as a mapping {track: array, "fps": n}: the group itself when it already is one, or what the loader
+// returns for the group's `trajectoryFile`
+py::object resolve_group(const py::object& group, const py::object& loader) {
+    std::string file;
+    if (PyParams(group).getParameter("trajectoryFile", file)) {
+        const py::object& l = loader.is_none() ? default_loader() : loader;
+        if (l.is_none())
+            throw std::invalid_argument("group holds trajectoryFile '" + file + "' but no trajectory loader is set "
+                                        "(setTrajectoryLoader / set_trajectory_loader)");
+        return l(file);
+    }
+    return group;
+}
 
 int fps_of(const py::object& group, int fallback) {
     try {
@@ -262,7 +285,8 @@ public:
         auto position = std::make_shared<Trajectory>();
         auto alpha = std::make_shared<Trajectory>();
         try {
-            const py::object pt = params.group("POSITION_TRAJECTORY"), tm = params.group("TRAJECTORY_MANAGER");
+            const py::object pt = resolve_group(params.group("POSITION_TRAJECTORY"), m_loader);
+            const py::object tm = resolve_group(params.group("TRAJECTORY_MANAGER"), m_loader);
             const int desPos = int(1.0 / periodLarge), desAlpha = int(1.0 / periodMPC);   // costsVSMPC.cpp:68, systemDynamicsVSMPC.cpp:272
             const int fpsPos = fps_of(pt, 10), fpsAlpha = fps_of(tm, 10);
             Arr pos = Arr::ensure(item(pt, "positionCoM"));
@@ -280,6 +304,7 @@ public:
         m_ref = std::make_unique<Surface>();
         m_ref->setTrajectories(position, alpha);
         m_ref->setDevice(device);
+        m_ref->setFusedTick(m_fused);
         PyQPInput qp(mpcInput);
         bool ok = false;
         try {
@@ -330,8 +355,12 @@ public:
         return py::array_t<double>(x.size() - off, x.data() + off);
     }
     py::array_t<double> final3(int off) const { return py::array_t<double>(3, tick().finalState().data() + off); }
+    void setTrajectoryLoader(py::object loader) { m_loader = std::move(loader); }
+    void setFusedTick(bool fused) { m_fused = fused; }
 
 private:
+    py::object m_loader = py::none();
+    bool m_fused = true;
     std::unique_ptr<Surface> m_ref;
     std::unique_ptr<vsmpc_host::VariableSamplingMPC> m_rec;
 };
@@ -340,12 +369,16 @@ private:
 
 PYBIND11_MODULE(bindingsMPC, m) {
     m.doc() = "MI355X-backed drop-in for momentum_based_mpc.bindingsMPC (VariableSamplingMPC only)";
+    m.def("set_trajectory_loader", [](py::object loader) { default_loader() = std::move(loader); }, py::arg("loader"),
+          "loader(trajectoryFile) -> {variable: array, 'fps': int}; used when a handler group holds `trajectoryFile`");
     py::class_<PyVariableSamplingMPC>(m, "VariableSamplingMPC")
         .def(py::init<>())
-        .def("configure", &PyVariableSamplingMPC::configureRecord, py::arg("parametersHandler"), py::arg("jointPositions"),
-             py::arg("initialRPY"), py::arg("device") = 0)                       // record level (tried first: needs a dict)
         .def("configure", &PyVariableSamplingMPC::configureReference, py::arg("parametersHandler"), py::arg("mpcInput"),
-             py::arg("device") = 0)                                              // MPCPyBindings.cpp:24-32
+             py::arg("device") = 0)                                              // MPCPyBindings.cpp:24-32 (tried first)
+        .def("configureRecord", &PyVariableSamplingMPC::configureRecord, py::arg("parametersHandler"), py::arg("jointPositions"),
+             py::arg("initialRPY"), py::arg("device") = 0)                       // record level: dict, 23 joints, RPY
+        .def("setTrajectoryLoader", &PyVariableSamplingMPC::setTrajectoryLoader, py::arg("loader"))
+        .def("setFusedTick", &PyVariableSamplingMPC::setFusedTick, py::arg("fused"))
         .def("update", &PyVariableSamplingMPC::update, py::arg("mpcInput"), py::arg("applyTickState") = false)
         .def("solveMPC", &PyVariableSamplingMPC::solveMPC)
         .def("getQPProblemStatus", &PyVariableSamplingMPC::status)

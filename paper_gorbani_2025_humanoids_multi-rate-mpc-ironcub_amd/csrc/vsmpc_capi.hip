@@ -41,7 +41,8 @@ struct vsmpc_handle {
     hipEvent_t pipe_start;
     // small batches through the host-pointer entry (the reference's own use: one instance per tick): pinned,
     // device-mapped staging that the kernel reads and writes directly, instead of five small copies
-    double* h_stage;      // host view:  in[ZC_MAX][n_in] | x[ZC_MAX][n_var] | fm[ZC_MAX][24] | status[ZC_MAX] | iters[ZC_MAX]
+    double* h_stage;      // host view:  in[ZC_MAX][n_in] | x[ZC_MAX][n_var] | fm[ZC_MAX][24] | status[ZC_MAX] | iters[ZC_MAX] |
+                          //             kin[ZC_MAX][VSMPC_KIN_SIZE] (vsmpc_tick)
     double* d_stage;      // device view of the same allocation (its own base pointer: the two views are unrelated addresses)
 };
 
@@ -80,6 +81,7 @@ struct vsmpc_rollout {
     hipStream_t own_stream;   // used when the caller passes the null stream (which cannot be captured)
     hipGraphExec_t gexec;     // GRAPH_TICKS ticks (3 launches each) captured once, replayed per chunk
     int graph_state;          // 0 not built yet, 1 ready, -1 capture unavailable (direct launches only)
+    int graph_form;           // h->form the graph was captured with (vsmpc_set_kernel_form on the handle rebuilds it)
 };
 
 namespace {
@@ -96,6 +98,23 @@ int hip_fail(hipError_t e, const char* what) {
         hipError_t _e = (expr);                         \
         if (_e != hipSuccess) return hip_fail(_e, #expr); \
     } while (0)
+
+#define ON_DEVICE(dev) DeviceScope _scope(dev); HIP_TRY(_scope.err)
+
+// carve-up of the mapped staging buffer (host or device view)
+struct Stage {
+    double* in; double* x; double* fm; int* st; int* it; double* kin;
+};
+Stage stage_view(const vsmpc_handle* h, double* base) {
+    Stage v;
+    v.in = base;
+    v.x = v.in + size_t(ZC_MAX) * h->n_in;
+    v.fm = v.x + size_t(ZC_MAX) * h->n_var;
+    v.st = reinterpret_cast<int*>(v.fm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
+    v.it = v.st + ZC_MAX;
+    v.kin = v.fm + size_t(ZC_MAX) * (VSMPC_FM_SIZE + 1);
+    return v;
+}
 
 // dt schedule: constraintsVSMPC.cpp:45-51 (beta1, beta2), :78-84, :156-159
 void fill_dt(const vsmpc_config& c, double* dt) {
@@ -158,7 +177,7 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(device));
+    ON_DEVICE(device);
 
     vsmpc_handle* h = new (std::nothrow) vsmpc_handle();
     if (h == nullptr) return VSMPC_ERR_ALLOC;
@@ -196,7 +215,7 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pipe_start, hipEventDisableTiming);
     if (e == hipSuccess) {
-        const size_t zc = size_t(ZC_MAX) * (h->n_in + h->n_var + VSMPC_FM_SIZE + 1) * sizeof(double);  // ints share one double
+        const size_t zc = size_t(ZC_MAX) * (h->n_in + h->n_var + VSMPC_FM_SIZE + 1 + VSMPC_KIN_SIZE) * sizeof(double);  // ints share one double
         e = hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), zc, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_stage), h->h_stage, 0);
     }
@@ -212,7 +231,7 @@ int vsmpc_create(const vsmpc_config* cfg, int device, int max_batch, vsmpc_handl
 
 void vsmpc_destroy(vsmpc_handle* h) {
     if (h == nullptr) return;
-    (void)hipSetDevice(h->device);
+    DeviceScope scope(h->device);
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_fm) (void)hipFree(h->d_fm);
@@ -246,15 +265,9 @@ int vsmpc_solve_batch_device(vsmpc_handle* h, const double* d_in, int batch, dou
     if (h == nullptr || d_in == nullptr || d_status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
-    // an enqueue-only entry must not change the caller's current device: set the handle's for the launch, put back the
-    // caller's afterwards (also on failure)
-    int caller_dev = -1;
-    HIP_TRY(hipGetDevice(&caller_dev));
-    if (caller_dev != h->device) HIP_TRY(hipSetDevice(h->device));
-    const hipError_t e = launch_solve(h->variant, h->form, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr,
-                                      nullptr, nullptr, static_cast<hipStream_t>(stream));
-    if (caller_dev != h->device) (void)hipSetDevice(caller_dev);
-    HIP_TRY(e);
+    ON_DEVICE(h->device);   // an enqueue-only entry must not change the caller's current device either
+    HIP_TRY(launch_solve(h->variant, h->form, h->dev, d_in, batch, d_x, d_first_move, d_status, d_iters, nullptr, nullptr, nullptr,
+                         static_cast<hipStream_t>(stream)));
     return VSMPC_OK;
 }
 
@@ -264,27 +277,18 @@ int vsmpc_solve_batch(vsmpc_handle* h, const double* in, int batch, double* x, d
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     const size_t B = size_t(batch);
     if (batch <= ZC_MAX) {
         // zero-copy path: the kernel reads the records from and writes the results to pinned host memory
-        double* hin = h->h_stage;
-        double* hx = hin + size_t(ZC_MAX) * h->n_in;
-        double* hfm = hx + size_t(ZC_MAX) * h->n_var;
-        int* hst = reinterpret_cast<int*>(hfm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
-        int* hit = hst + ZC_MAX;
-        double* din = h->d_stage;                              // the same carve-up on the device view
-        double* dx = din + size_t(ZC_MAX) * h->n_in;
-        double* dfm = dx + size_t(ZC_MAX) * h->n_var;
-        int* dst = reinterpret_cast<int*>(dfm + size_t(ZC_MAX) * VSMPC_FM_SIZE);
-        int* dit = dst + ZC_MAX;
-        memcpy(hin, in, B * h->n_in * sizeof(double));
-        HIP_TRY(launch_solve(h->variant, h->form, h->dev, din, batch, dx, dfm, dst, dit, nullptr, nullptr, nullptr, s));
+        const Stage hv = stage_view(h, h->h_stage), dv = stage_view(h, h->d_stage);   // the same carve-up on both views
+        memcpy(hv.in, in, B * h->n_in * sizeof(double));
+        HIP_TRY(launch_solve(h->variant, h->form, h->dev, dv.in, batch, dv.x, dv.fm, dv.st, dv.it, nullptr, nullptr, nullptr, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (x) memcpy(x, hx, B * h->n_var * sizeof(double));
-        if (first_move) memcpy(first_move, hfm, B * VSMPC_FM_SIZE * sizeof(double));
-        memcpy(status, hst, B * sizeof(int));
-        if (iters) memcpy(iters, hit, B * sizeof(int));
+        if (x) memcpy(x, hv.x, B * h->n_var * sizeof(double));
+        if (first_move) memcpy(first_move, hv.fm, B * VSMPC_FM_SIZE * sizeof(double));
+        memcpy(status, hv.st, B * sizeof(int));
+        if (iters) memcpy(iters, hv.it, B * sizeof(int));
         return VSMPC_OK;
     }
     // Pinned output buffers (hipHostMalloc / vsmpc_alloc_host) are written by the kernel itself over PCIe (16 B per lane
@@ -350,7 +354,7 @@ int vsmpc_linearize_batch(vsmpc_handle* h, const double* in, int batch, double* 
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (dt) fill_dt(h->cfg, dt);
     if (batch == 0) return VSMPC_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     const size_t B = size_t(batch);
     double* dA = h->d_lin;
     double* dBj = dA + size_t(h->max_batch) * NX * NX;
@@ -460,7 +464,7 @@ int vsmpc_assemble_dense(vsmpc_handle* h, const double* in_one, double* H, doubl
 
 int vsmpc_debug_condensed(vsmpc_handle* h, const double* in_one, double* M, double* Lfac) {
     if (h == nullptr || in_one == nullptr) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     const size_t np2 = size_t(h->n_p) * h->n_p;
     HIP_TRY(hipMemcpy(h->d_in, in_one, h->n_in * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->d_dbg, 0, 2 * np2 * sizeof(double)));   // the kernel writes the lower triangles only
@@ -476,7 +480,7 @@ int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double
     if (h == nullptr || kin == nullptr || out == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     HIP_TRY(hipMemcpy(h->d_kin, kin, size_t(batch) * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(launch_kinematics(h->d_kin, batch, h->d_kout, h->kin, nullptr));
     HIP_TRY(hipDeviceSynchronize());
@@ -493,11 +497,54 @@ int vsmpc_kinematics_batch(vsmpc_handle* h, const double* kin, int batch, double
     return VSMPC_OK;
 }
 
+// One tick of the reference's drop-in surface in ONE submission: kinematics terms -> record -> solve, one synchronisation.
+int vsmpc_tick(vsmpc_handle* h, const double* kin, double* in, int batch, double* x, double* first_move, int* status,
+               int* iters, void* stream) {
+    if (h == nullptr || kin == nullptr || in == nullptr || status == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
+    if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
+    if (batch == 0) return VSMPC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ON_DEVICE(h->device);
+    const size_t B = size_t(batch);
+    if (batch <= ZC_MAX) {
+        // the kinematics kernel reads the raw Robot quantities from, and writes LLIN | LANG | INERTIA into, the mapped
+        // staging buffer; the solve kernel (next in stream order) reads the completed record from there
+        const Stage hv = stage_view(h, h->h_stage), dv = stage_view(h, h->d_stage);
+        memcpy(hv.kin, kin, B * VSMPC_KIN_SIZE * sizeof(double));
+        memcpy(hv.in, in, B * h->n_in * sizeof(double));
+        HIP_TRY(launch_kinematics_patch(dv.kin, batch, dv.in, h->n_in, h->kin, s));
+        HIP_TRY(launch_solve(h->variant, h->form, h->dev, dv.in, batch, dv.x, dv.fm, dv.st, dv.it, nullptr, nullptr, nullptr, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t b = 0; b < B; ++b)   // hand the completed fields back (the caller's record is the record of the tick)
+            memcpy(in + b * h->n_in + VSMPC_IN_LLIN, hv.in + b * h->n_in + VSMPC_IN_LLIN, (24 + 24 + 9) * sizeof(double));
+        if (x) memcpy(x, hv.x, B * h->n_var * sizeof(double));
+        if (first_move) memcpy(first_move, hv.fm, B * VSMPC_FM_SIZE * sizeof(double));
+        memcpy(status, hv.st, B * sizeof(int));
+        if (iters) memcpy(iters, hv.it, B * sizeof(int));
+        return VSMPC_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_kin, kin, B * VSMPC_KIN_SIZE * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_in, in, B * h->n_in * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_kinematics_patch(h->d_kin, batch, h->d_in, h->n_in, h->kin, s));
+    HIP_TRY(launch_solve(h->variant, h->form, h->dev, h->d_in, batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr, nullptr,
+                         nullptr, s));
+    HIP_TRY(hipMemcpyAsync(in, h->d_in, B * h->n_in * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (x) HIP_TRY(hipMemcpyAsync(x, h->d_x, B * h->n_var * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (first_move) HIP_TRY(hipMemcpyAsync(first_move, h->d_fm, B * VSMPC_FM_SIZE * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(status, h->d_status, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, h->d_iters, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return VSMPC_OK;
+}
+
 int vsmpc_provider_batch(vsmpc_handle* h, const vsmpc_tree* tree, const double* state, int batch, double* kin,
                          double* robot, double* records) {
     if (h == nullptr || tree == nullptr || state == nullptr || batch < 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (batch == 0) return VSMPC_OK;
+    // the provider delivers the CURRENT frame Jacobians; jointsLambdaOption "constant" re-reads those slots as the
+    // configure-time relative Jacobians and thrusts (vsmpc_set_kinematics_options): the combination has no meaning
+    if (records != nullptr && h->kin.constant_lambda) return VSMPC_ERR_UNSUPPORTED_CONFIG;
     if (tree->parent[0] != -1) return VSMPC_ERR_INVALID_ARG;
     for (int b = 1; b < VSMPC_TREE_NB; ++b)
         if (tree->parent[b] < 0 || tree->parent[b] >= b) return VSMPC_ERR_INVALID_ARG;      // parents precede children
@@ -505,7 +552,7 @@ int vsmpc_provider_batch(vsmpc_handle* h, const vsmpc_tree* tree, const double* 
         if (tree->robot_joint[j] < 0 || tree->robot_joint[j] >= VSMPC_KIN_NJ) return VSMPC_ERR_INVALID_ARG;
     for (int i = 0; i < VSMPC_N_THRUSTS; ++i)
         if (tree->jet_body[i] < 0 || tree->jet_body[i] >= VSMPC_TREE_NB) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     // scratch: the state records go through d_lin (1014 doubles per instance), the Robot-level outputs through d_x
     // (n_var >= 67 doubles per instance), the kinematics record through d_kin
     double* d_state = h->d_lin;
@@ -539,7 +586,7 @@ int vsmpc_set_kinematics_options(vsmpc_handle* h, const int* joint_selector, int
 int vsmpc_debug_phase_cycles(vsmpc_handle* h, const double* in, int batch, unsigned long long* stamps16) {
     if (h == nullptr || in == nullptr || stamps16 == nullptr || batch <= 0) return VSMPC_ERR_INVALID_ARG;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     unsigned long long* d_st = h->d_stamps;
     HIP_TRY(hipMemset(d_st, 0, size_t(batch) * 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemcpy(h->d_in, in, size_t(batch) * h->n_in * sizeof(double), hipMemcpyHostToDevice));
@@ -576,7 +623,7 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
         return VSMPC_ERR_INVALID_ARG;
     *out = nullptr;
     if (batch > h->max_batch) return VSMPC_ERR_BATCH_TOO_LARGE;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     vsmpc_rollout* r = new (std::nothrow) vsmpc_rollout();
     if (r == nullptr) return VSMPC_ERR_ALLOC;
     memset(r, 0, sizeof(*r));
@@ -624,7 +671,7 @@ int vsmpc_rollout_create(vsmpc_handle* h, int batch, const double* traj_pos, con
 
 void vsmpc_rollout_destroy(vsmpc_rollout* r) {
     if (r == nullptr) return;
-    (void)hipSetDevice(r->h->device);
+    DeviceScope scope(r->h->device);
     if (r->d_state) (void)hipFree(r->d_state);
     if (r->d_params) (void)hipFree(r->d_params);
     if (r->d_tick) (void)hipFree(r->d_tick);
@@ -644,7 +691,7 @@ void vsmpc_rollout_destroy(vsmpc_rollout* r) {
 
 int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* params) {
     if (r == nullptr || state == nullptr || params == nullptr) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(r->h->device));
+    ON_DEVICE(r->h->device);
     const size_t B = size_t(r->batch);
     HIP_TRY(hipMemcpy(r->d_state, state, B * VSMPC_PLANT_STATE * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(r->d_params, params, B * VSMPC_PLANT_PARAMS * sizeof(double), hipMemcpyHostToDevice));
@@ -661,8 +708,12 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
 
 int vsmpc_rollout_set_attitude_tracks(vsmpc_rollout* r, const double* traj_rpy, const double* traj_rpy_dot) {
     if (r == nullptr) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(r->h->device));
+    ON_DEVICE(r->h->device);
     const size_t bytes = size_t(r->rd.n_traj) * 3 * sizeof(double);
+    // whatever happens below, the captured ticks and the record of the next tick refer to the old tracks: drop them first
+    if (r->gexec) { (void)hipGraphExecDestroy(r->gexec); r->gexec = nullptr; }
+    r->graph_state = 0;
+    r->valid = 0;                                                                // vsmpc_rollout_reset before the next run
     auto set = [&](double*& dst, const double* src) -> hipError_t {
         if (src == nullptr) {
             if (dst) (void)hipFree(dst);
@@ -671,17 +722,16 @@ int vsmpc_rollout_set_attitude_tracks(vsmpc_rollout* r, const double* traj_rpy, 
         }
         if (dst == nullptr) {
             hipError_t e = hipMalloc(&dst, bytes);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess) { dst = nullptr; return e; }
         }
         return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     };
-    HIP_TRY(set(r->d_trpy, traj_rpy));
-    HIP_TRY(set(r->d_trpyd, traj_rpy_dot));
-    r->rd.traj_rpy = r->d_trpy;
+    const hipError_t e0 = set(r->d_trpy, traj_rpy);
+    r->rd.traj_rpy = r->d_trpy;              // (a failed set leaves either the old, still valid buffer or nullptr)
+    HIP_TRY(e0);
+    const hipError_t e1 = set(r->d_trpyd, traj_rpy_dot);
     r->rd.traj_rpyd = r->d_trpyd;
-    if (r->gexec) { (void)hipGraphExecDestroy(r->gexec); r->gexec = nullptr; }   // the captured ticks hold the old arguments
-    r->graph_state = 0;
-    r->valid = 0;                                                                // vsmpc_rollout_reset before the next run
+    HIP_TRY(e1);
     return VSMPC_OK;
 }
 
@@ -729,6 +779,7 @@ hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
 // tick base live in device memory).  Launch-bound loop -> one graph launch per chunk instead of 50 kernel launches.
 void build_tick_graph(vsmpc_rollout* r, hipStream_t s) {
     r->graph_state = -1;
+    r->graph_form = r->h->form;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
     hipError_t e = hipSuccess;
     for (int t = 0; t < GRAPH_TICKS && e == hipSuccess; ++t) e = enqueue_tick(r, s);
@@ -751,7 +802,7 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
     if (!r->valid) return VSMPC_ERR_INVALID_ARG;   // never reset, or a previous run failed half-way: reset() first
     if (ticks == 0) return VSMPC_OK;
     vsmpc_handle* h = r->h;
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->own_stream;
     const size_t row = size_t(r->batch) * VSMPC_ROLLOUT_LOG;
     if (log != nullptr && r->log_ticks < ticks) {
@@ -767,6 +818,10 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
     HIP_TRY(hipStreamSynchronize(s));  // `ctl` lives on this stack frame
     r->valid = 0;                       // until the whole run has completed: a failure below leaves the counters ahead
     int t = 0;
+    if (r->graph_state != 0 && r->graph_form != h->form) {   // the captured launches are of the other condensing form
+        if (r->gexec) { (void)hipGraphExecDestroy(r->gexec); r->gexec = nullptr; }
+        r->graph_state = 0;
+    }
     if (ticks >= GRAPH_TICKS && r->graph_state == 0) build_tick_graph(r, s);
     if (r->graph_state == 1)
         for (; ticks - t >= GRAPH_TICKS; t += GRAPH_TICKS) HIP_TRY(hipGraphLaunch(r->gexec, s));
@@ -780,14 +835,14 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream) {
 
 int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state) {
     if (r == nullptr || state == nullptr) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(r->h->device));
+    ON_DEVICE(r->h->device);
     HIP_TRY(hipMemcpy(state, r->d_state, size_t(r->batch) * VSMPC_PLANT_STATE * sizeof(double), hipMemcpyDeviceToHost));
     return VSMPC_OK;
 }
 
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records) {
     if (r == nullptr || records == nullptr) return VSMPC_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(r->h->device));
+    ON_DEVICE(r->h->device);
     HIP_TRY(hipMemcpy(records, r->d_rec, size_t(r->batch) * r->h->n_in * sizeof(double), hipMemcpyDeviceToHost));
     return VSMPC_OK;
 }

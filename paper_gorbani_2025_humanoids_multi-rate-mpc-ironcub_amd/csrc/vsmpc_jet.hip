@@ -195,7 +195,7 @@ int vsmpc_jet_create(const float* w_ih, const float* w_hh, const float* b_ih, co
     int ndev = 0;
     JET_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return VSMPC_ERR_INVALID_ARG;
-    JET_TRY(hipSetDevice(device));
+    vsmpc::DeviceScope _scope(device); JET_TRY(_scope.err);
     vsmpc_jet* j = new (std::nothrow) vsmpc_jet();
     if (!j) return VSMPC_ERR_ALLOC;
     *j = vsmpc_jet{};
@@ -243,7 +243,7 @@ int vsmpc_jet_create(const float* w_ih, const float* w_hh, const float* b_ih, co
 
 void vsmpc_jet_destroy(vsmpc_jet* j) {
     if (!j) return;
-    (void)hipSetDevice(j->device);
+    vsmpc::DeviceScope _scope(j->device);
     void* ptrs[] = {j->d_w, j->d_whhT, j->d_f0, j->d_f1, j->d_f2, j->d_f3, j->d_h, j->d_c, j->d_x, j->d_P, j->d_u, j->d_z,
                     j->d_log, j->d_thr_steps};
     for (void* p : ptrs)
@@ -256,7 +256,7 @@ int vsmpc_jet_nn_step(vsmpc_jet* j, const float* thrust, const float* throttle, 
     if (!j || !thrust || !throttle || !T_next || !T_dot || n < 0) return VSMPC_ERR_INVALID_ARG;
     if (n > j->max_series) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (n == 0) return VSMPC_OK;
-    JET_TRY(hipSetDevice(j->device));
+    vsmpc::DeviceScope _scope(j->device); JET_TRY(_scope.err);
     const size_t N = size_t(n);
     JET_TRY(hipMemcpy(j->d_f0, thrust, N * sizeof(float), hipMemcpyHostToDevice));
     JET_TRY(hipMemcpy(j->d_f1, throttle, N * sizeof(float), hipMemcpyHostToDevice));
@@ -276,7 +276,7 @@ int vsmpc_jet_nn_sequence(vsmpc_jet* j, const float* x, int n, int L, float dt, 
     if (!j || !x || !T_next_norm || !T_dot_norm || n < 0 || L <= 0) return VSMPC_ERR_INVALID_ARG;
     if (n > j->max_series) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (n == 0) return VSMPC_OK;
-    JET_TRY(hipSetDevice(j->device));
+    vsmpc::DeviceScope _scope(j->device); JET_TRY(_scope.err);
     float* d_x = nullptr;                       // sequences are a parity / offline entry: sized per call
     JET_TRY(hipMalloc(&d_x, size_t(n) * L * 2 * sizeof(float)));
     hipError_t e = hipMemcpy(d_x, x, size_t(n) * L * 2 * sizeof(float), hipMemcpyHostToDevice);
@@ -302,7 +302,7 @@ int vsmpc_jet_ekf_update(vsmpc_jet* j, double* x, double* P, const double* u, co
     if (!j || !x || !P || !u || !z || !Q || !R || n < 0 || !(dt > 0.0)) return VSMPC_ERR_INVALID_ARG;
     if (n > j->max_series) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (n == 0) return VSMPC_OK;
-    JET_TRY(hipSetDevice(j->device));
+    vsmpc::DeviceScope _scope(j->device); JET_TRY(_scope.err);
     const size_t N = size_t(n);
     JET_TRY(hipMemcpy(j->d_x, x, N * 2 * sizeof(double), hipMemcpyHostToDevice));
     JET_TRY(hipMemcpy(j->d_P, P, N * 4 * sizeof(double), hipMemcpyHostToDevice));
@@ -324,7 +324,7 @@ int vsmpc_jet_plant_run_device(vsmpc_jet* j, float* d_T_nn, double* d_x_est, dou
         (throttle_steps != 1 && throttle_steps != steps))
         return VSMPC_ERR_INVALID_ARG;
     if (n == 0 || steps == 0) return VSMPC_OK;
-    JET_TRY(hipSetDevice(j->device));
+    vsmpc::DeviceScope _scope(j->device); JET_TRY(_scope.err);
     hipLaunchKernelGGL(jet_plant_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), j->d_w,
                        j->hidden, j->nm, d_T_nn, d_x_est, d_P, d_throttle, throttle_steps, n, steps, dt, make_cov(Q, R), d_log);
     JET_TRY(hipGetLastError());
@@ -338,7 +338,7 @@ int vsmpc_jet_plant_run(vsmpc_jet* j, float* T_nn, double* x_est, double* P, con
         return VSMPC_ERR_INVALID_ARG;
     if (n > j->max_series) return VSMPC_ERR_BATCH_TOO_LARGE;
     if (n == 0 || steps == 0) return VSMPC_OK;
-    JET_TRY(hipSetDevice(j->device));
+    vsmpc::DeviceScope _scope(j->device); JET_TRY(_scope.err);
     const size_t N = size_t(n), TS = size_t(throttle_steps) * N;
     if (TS > j->thr_floats) {              // grows only when a longer schedule than ever before is passed
         if (j->d_thr_steps) (void)hipFree(j->d_thr_steps);

@@ -37,6 +37,7 @@
 // VALU work does not hide under it (shared FP64 datapath); a dependent vector instruction issues every 8-10 cycles, a
 // v_readlane takes ~32 cycles to land, v_readlane pair + FMA ~21.6 per update.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
 // streams carry nothing but operand loads.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -3007,13 +3008,15 @@ static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
                                  unsigned long long* stamps, hipStream_t stream) {
     // the dynamic-LDS limit is a per-device function attribute: one process may drive several devices
-    static bool attr_set[MAX_DEVICES] = {};
+    // (two host threads with their own handles may arrive here together: the flag is atomic, setting the attribute twice
+    // is harmless, and it is published only after the call has succeeded)
+    static std::atomic<bool> attr_set[MAX_DEVICES];
     constexpr size_t lds = FORM == 1 ? Smem<D>::bytes_struct : Smem<D>::bytes;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<D, STAMPS, FORM, PLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((solve_kernel<D, STAMPS, FORM, PLDS>), dim3(batch), dim3(D::BLOCK), lds, stream,
                        cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL, stamps);
@@ -3032,15 +3035,17 @@ static hipError_t launch_solve_t(int form, const DevCfg& cfg, const double* d_in
         if (form != 2) {
             // two workgroups per CU once the batch exceeds the CUs: the panel streams with LDS broadcasts (see panel_factor)
             if constexpr (D::WG_PER_CU == 2 && !STAMPS) {
-                static int cus[MAX_DEVICES] = {};
-                if (cus[dev] == 0) {
+                static std::atomic<int> cus[MAX_DEVICES];
+                int ncu = cus[dev].load(std::memory_order_relaxed);
+                if (ncu == 0) {
                     int n = 0;
                     e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
                     if (e != hipSuccess) return e;
-                    cus[dev] = n > 0 ? n : 1;
+                    ncu = n > 0 ? n : 1;
+                    cus[dev].store(ncu, std::memory_order_relaxed);
                 }
                 const char* pv = getenv("VSMPC_PANEL");   // measurements: lds | readlane
-                const bool lds = pv != nullptr ? pv[0] == 'l' : batch > cus[dev];
+                const bool lds = pv != nullptr ? pv[0] == 'l' : batch > ncu;
                 if (lds)
                     return launch_solve_f<D, STAMPS, 1, true>(dev, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,
                                                               stamps, stream);

@@ -9,6 +9,20 @@ struct vsmpc_jet;   // include/vsmpc_jet.h
 
 namespace vsmpc {
 
+// Entry points that must run on the handle's device switch to it for their own duration only: the caller's current device
+// is put back on every return path (a library call that silently re-targets the caller's later HIP calls is a bug).
+struct DeviceScope {
+    int caller = -1, target = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device) : target(device) {
+        err = hipGetDevice(&caller);
+        if (err == hipSuccess && caller != target) err = hipSetDevice(target);
+    }
+    ~DeviceScope() { if (caller >= 0 && caller != target) (void)hipSetDevice(caller); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 enum Variant { VARIANT_NONE = 0 };  // 1.. = position in csrc/vsmpc_horizons.def
 
 int select_variant(int n_iter, int n_iter_small, int control_horizon);

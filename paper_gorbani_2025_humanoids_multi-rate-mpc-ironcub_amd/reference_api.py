@@ -168,6 +168,22 @@ class VariableSamplingMPC:
         self._solver = None
         self._status = 0
 
+    trajectory_loader = None   # loader(trajectoryFile) -> {variable: array, "fps": int}; trajectory_io.load_mat_trajectory
+
+    def setTrajectoryLoader(self, loader):
+        self.trajectory_loader = loader
+
+    def _resolve_group(self, group):
+        """a trajectory group as a mapping of arrays: the group itself, or -- when it holds a `trajectoryFile` name like the
+        handler the harness reads from XML (src/config/vs_mcp_config.xml:34-40) -- what the loader returns for it"""
+        try:
+            name = _param(group, "trajectoryFile", kind="str")
+        except (KeyError, ValueError, TypeError):
+            return group
+        if self.trajectory_loader is None:
+            raise ValueError(f"group holds trajectoryFile '{name}' but no trajectory loader is set (setTrajectoryLoader)")
+        return self.trajectory_loader(name)
+
     # ------------------------------------------------------------------ configure (IMPCProblem.cpp:3-148)
     def configure(self, parametersHandler, qpInput) -> bool:
         try:
@@ -192,7 +208,7 @@ class VariableSamplingMPC:
                 raise ValueError("Parameter 'jointsLambdaOption' should be 'unfiltered' or 'constant'.")
             self._constantLambda = option == "constant"
             self._controlledJoints = list(_param(h, "controlledJoints", [], kind="strvec"))
-            tm, pt = _group(h, "TRAJECTORY_MANAGER"), _group(h, "POSITION_TRAJECTORY")
+            tm, pt = self._resolve_group(_group(h, "TRAJECTORY_MANAGER")), self._resolve_group(_group(h, "POSITION_TRAJECTORY"))
             self._alpha = _Track({"alphaGravity": np.asarray(tm["alphaGravity"], float).reshape(-1)}, int(tm.get("fps", 10)),
                                  int(1 / cfg.period_mpc))                                    # systemDynamicsVSMPC.cpp:272
             n = len(pt["positionCoM"])

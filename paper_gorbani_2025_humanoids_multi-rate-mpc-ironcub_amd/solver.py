@@ -151,6 +151,22 @@ class BatchedVSMPC:
                    "vsmpc_kinematics_batch")
         return out[:, 0:24].reshape(-1, 3, 8), out[:, 24:48].reshape(-1, 3, 8), out[:, 48:57].reshape(-1, 3, 3)
 
+    def tick(self, kin: np.ndarray, records: np.ndarray):
+        """vsmpc_tick: kinematics terms -> records -> solve in one submission (one synchronisation).  `records` is completed
+        in place (LLIN | LANG | INERTIA).  Returns (x, first_move, status, iters) like solve()."""
+        kin = np.ascontiguousarray(kin, dtype=np.float64)
+        n = kin.shape[0]
+        if kin.ndim != 2 or kin.shape[1] != L.KIN_SIZE:
+            raise ValueError(f"kin must be [batch, {L.KIN_SIZE}]")
+        assert records.dtype == np.float64 and records.flags["C_CONTIGUOUS"] and records.shape == (n, self.n_in)
+        x = np.empty((n, self.n_var))
+        fm = np.empty((n, L.FM_SIZE))
+        st = np.zeros(n, dtype=np.int32)
+        it = np.zeros(n, dtype=np.int32)
+        _lib.check(self.lib.vsmpc_tick(self._h, _ptr(kin), _ptr(records), n, _ptr(x), _ptr(fm), _ptr(st), _ptr(it), None),
+                   "vsmpc_tick")
+        return x, fm, st, it
+
     def provider(self, tree: dict, states: np.ndarray, records: np.ndarray | None = None):
         """vsmpc_provider_batch: the Robot quantities of the path on the simplified tree (robot_tree.py).  Returns
         (kin[batch, KIN_SIZE], robot[batch, RO_SIZE]); `records`, when given, get the Robot-derived fields patched in

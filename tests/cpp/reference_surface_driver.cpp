@@ -1,139 +1,32 @@
-// Drives vsmpc_host::VariableSamplingMPCT -- the reference's configure(parametersHandler, qpInput) / update(qpInput) /
-// solveMPC() surface (include/VariableSamplingMPC.hpp) -- with FAKE provider classes that expose exactly the members of
-// utils/include/Robot.h, utils/include/QPInput.h:12-124 and BLF's IParametersHandler::getParameter the path touches
-// (element access through operator(), like Eigen / iDynTree), fed from a scenario file written by the Python test.
-//   reference_surface_driver <scenario.bin> <out.bin>
+// Drives vsmpc_host::VariableSamplingMPCT<QPInput, TrajectoryManager> -- the reference-side binding of INTEGRATION.md
+// section 2, through tests/cpp/integration_snippet.cpp VERBATIM -- against signature-exact stand-ins of the reference's
+// headers (tests/cpp/refstub/: Eigen-typed QPInput setters, an Eigen::VectorXd-returning TrajectoryManager without has(),
+// a weak_ptr<IParametersHandler>; see its README), fed from a scenario file written by the Python test.  If the header
+// assumed anything the reference's declarations do not offer, this file would not BUILD.
+//   reference_surface_driver <scenario.bin> <out.bin> [two-call]
+//   reference_surface_driver <scenario.bin> - latency <ticks> [two-call]   -> one JSON line: p50 / p99 / mean wall-clock of
+//       update(qpInput) + solveMPC() per tick (std::chrono around the two calls only; loading the provider state into the
+//       stand-in Robot is the provider's work and outside the timed region); bench.py's latency_reference_surface_us
 // Scenario (doubles): header[16] | trajectories | config | controlled-joint indices[8] | initial QPInput | per tick
 // (configure-time first): robot block (+ reference-robot block when header says the two differ) + estimatedThrustDot[4].
 // Output per tick: record[n_in] | status | thrust[4] | thrustDot[4] | throttle[4] | joints[23] | posCoMRef[3] | rpyRef[3] |
 // alpha | momentumRef[6].
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <map>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
 
-#include "VariableSamplingMPC.hpp"
+#include "integration_snippet.cpp"   // the INTEGRATION.md snippet, verbatim (includes VariableSamplingMPC.hpp, QPInput.h, ...)
 
-namespace fake {
-
-struct Vec {   // Eigen::VectorXd / iDynTree::Vector3-like
-    std::vector<double> v;
-    double operator()(int i) const { return v[i]; }
-    double& operator()(int i) { return v[i]; }
-    int size() const { return int(v.size()); }
-};
-struct Mat {   // Eigen::MatrixXd / iDynTree::Rotation-like, row-major storage
-    int r = 0, c = 0;
-    std::vector<double> v;
-    double operator()(int i, int j) const { return v[size_t(i) * c + j]; }
-};
-struct Transform {
-    Vec pos; Mat rot;
-    const Vec& getPosition() const { return pos; }
-    const Mat& getRotation() const { return rot; }
-};
-struct Twist {
-    Vec lin, ang;
-    const Vec& getLinearVec3() const { return lin; }
-    const Vec& getAngularVec3() const { return ang; }
-};
-
-constexpr int NJ = 23, NJETS = 4;
-constexpr int ROBOT_BLOCK = 3 + 3 + 9 + 3 + 6 + 4 + NJ + 12 + 12 + 4 * 6 * NJ + 4 * 6 * (6 + NJ) + 3 * (6 + NJ) + 36 + 24 + 1 + 3;
-
-class Robot {   // the getters of utils/include/Robot.h the path uses
-public:
-    void load(const double* b) {
-        auto take = [&](int n) { std::vector<double> o(b, b + n); b += n; return o; };
-        com.v = take(3); pose.pos.v = take(3);
-        pose.rot.r = pose.rot.c = 3; pose.rot.v = take(9);
-        vel.ang.v = take(3); vel.lin.v = {0, 0, 0};
-        mom.v = take(6); thrust.v = take(4); q.v = take(NJ);
-        axes.assign(NJETS, Vec{}); arms.assign(NJETS, Vec{});
-        for (auto& a : axes) a.v = take(3);
-        for (auto& a : arms) a.v = take(3);
-        rel.assign(NJETS, Mat{});
-        for (auto& m : rel) { m.r = 6; m.c = NJ; m.v = take(6 * NJ); }
-        jac.assign(NJETS, Mat{});
-        for (auto& m : jac) { m.r = 6; m.c = 6 + NJ; m.v = take(6 * (6 + NJ)); }
-        jcom.r = 3; jcom.c = 6 + NJ; jcom.v = take(3 * (6 + NJ));
-        M.r = 6; M.c = 6; M.v = take(36);   // (only the base block is ever read)
-        amom.r = 6; amom.c = 4; amom.v = take(24);
-        mass = *b++; grav.v = take(3);
-    }
-    size_t getNJoints() const { return NJ; }
-    size_t getNJets() const { return NJETS; }
-    double getTotalMass() const { return mass; }
-    Transform getBasePose() const { return pose; }
-    Twist getBaseVel() const { return vel; }
-    const Vec& getPositionCoM() const { return com; }
-    const Vec& getMomentum(bool inBodyCoord = false) const { if (!inBodyCoord) std::abort(); return mom; }
-    const Vec& getGravity() const { return grav; }
-    const Vec& getJetThrusts() const { return thrust; }
-    const Vec& getJointPos() const { return q; }
-    const Mat& getMassMatrix() const { return M; }
-    const Mat& getMatrixAmomJets(bool inBodyCoord = false) const { if (!inBodyCoord) std::abort(); return amom; }
-    std::vector<Vec> getMatrixOfJetAxes() const { return axes; }
-    const std::vector<Vec>& getMatrixOfJetArms() const { return arms; }
-    const std::vector<Mat>& getRelativeJacobianJetsBodyFrame() const { return rel; }
-    const std::vector<std::string>& getJetsList() const { return jets; }
-    Mat getJacobian(const std::string& frameName) {
-        for (int i = 0; i < NJETS; ++i) if (jets[i] == frameName) return jac[i];
-        std::abort();
-    }
-    const Mat& getJacobianCoM() const { return jcom; }
-    std::string getJointName(int i) const { return "joint_" + std::to_string(i); }
-
-private:
-    Vec com, mom, thrust, q, grav;
-    Transform pose; Twist vel;
-    std::vector<Vec> axes, arms;
-    std::vector<Mat> rel, jac;
-    Mat jcom, M, amom;
-    double mass = 0.0;
-    std::vector<std::string> jets{"l_arm_jet_turbine", "r_arm_jet_turbine", "chest_l_jet_turbine", "chest_r_jet_turbine"};
-};
-
-class QPInput {   // utils/include/QPInput.h: the members the path touches
-public:
-    std::shared_ptr<Robot> getRobot() const { return robot; }
-    std::shared_ptr<Robot> getRobotReference() const { return robotReference; }
-    const Vec& getThrottleMPC() const { return throttleMPC; }
-    const Vec& getThrustDesMPC() const { return thrustDesMPC; }
-    const Vec& getThrustDotDesMPC() const { return thrustDotDesMPC; }
-    const Vec& getEstimatedThrustDot() const { return estimatedThrustDot; }
-    const Vec& getOutputQPJointsPosition() const { return outputQPJointsPosition; }
-    const Vec& getPosCoMReference() const { return posCoMReference; }
-    const Vec& getRPYReference() const { return rpyReference; }
-    void setPosCoMReference(const double* v) { posCoMReference.v.assign(v, v + 3); }
-    void setRPYReference(const double* v) { rpyReference.v.assign(v, v + 3); }
-    void setMomentumReference(const double* v) { momentumReference.v.assign(v, v + 6); }
-    void setAlphaGravity(double a) { alphaGravity = a; }
-
-    std::shared_ptr<Robot> robot, robotReference;
-    Vec throttleMPC{{0, 0, 0, 0}}, thrustDesMPC{{0, 0, 0, 0}}, thrustDotDesMPC{{0, 0, 0, 0}}, estimatedThrustDot{{0, 0, 0, 0}};
-    Vec outputQPJointsPosition{std::vector<double>(NJ, 0.0)};
-    Vec posCoMReference{{0, 0, 0}}, rpyReference{{0, 0, 0}}, momentumReference{std::vector<double>(6, 0.0)};
-    double alphaGravity = 0.0;
-};
-
-class ParametersHandler {   // BLF IParametersHandler::getParameter(name, value) -> bool
-public:
-    std::map<std::string, double> scalars;
-    std::map<std::string, std::vector<double>> vectors;
-    std::map<std::string, std::string> strings;
-    std::map<std::string, std::vector<std::string>> stringLists;
-    bool getParameter(const std::string& k, int& v) const { auto it = scalars.find(k); if (it == scalars.end()) return false; v = int(it->second); return true; }
-    bool getParameter(const std::string& k, double& v) const { auto it = scalars.find(k); if (it == scalars.end()) return false; v = it->second; return true; }
-    bool getParameter(const std::string& k, bool& v) const { auto it = scalars.find(k); if (it == scalars.end()) return false; v = it->second != 0.0; return true; }
-    bool getParameter(const std::string& k, std::string& v) const { auto it = strings.find(k); if (it == strings.end()) return false; v = it->second; return true; }
-    bool getParameter(const std::string& k, std::vector<double>& v) const { auto it = vectors.find(k); if (it == vectors.end()) return false; v = it->second; return true; }
-    bool getParameter(const std::string& k, std::vector<std::string>& v) const { auto it = stringLists.find(k); if (it == stringLists.end()) return false; v = it->second; return true; }
-};
-
-}  // namespace fake
+// compile-time pins of what the stand-ins (and hence the reference) do NOT convert from
+static_assert(!std::is_convertible<const double*, Eigen::Ref<const Eigen::Vector3d>>::value, "refstub: double* must not convert to Ref");
+static_assert(!std::is_convertible<double (&)[6], const Eigen::Vector6d&>::value, "refstub: double[6] must not convert to Vector6d");
+static_assert(std::is_same<decltype(std::declval<const TrajectoryManager&>().getCurrentValue(std::string())), Eigen::VectorXd>::value,
+              "getCurrentValue returns by value");
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
@@ -154,85 +47,142 @@ int main(int argc, char** argv) {
     const double* rpyTrack = p; p += 3 * nPos;
     const double* rpyDotTrack = p; p += 3 * nPos;
     const double* alphaTrack = p; p += nAlpha;
-    fake::ParametersHandler h;
+    using BipedalLocomotion::ParametersHandler::YarpImplementation;
+    auto handler = std::make_shared<YarpImplementation>();
+    YarpImplementation& h = *handler;
     const char* scalarKeys[] = {"nIter", "nIterSmall", "controlHorizon", "useJetDynamic", "periodMPC", "periodMPCSmallSteps",
                                 "periodMPCLargeSteps"};
-    for (const char* k : scalarKeys) h.scalars[k] = *p++;
+    double periodMPC = 0.0, periodLarge = 0.0;
+    for (const char* k : scalarKeys) {
+        if (!std::strcmp(k, "periodMPC")) periodMPC = *p;
+        if (!std::strcmp(k, "periodMPCLargeSteps")) periodLarge = *p;
+        h.testSet(k, *p++);
+    }
+    (void)periodMPC; (void)periodLarge;
     const char* vecKeys[] = {"weightCoMPos", "weightCoMPosError", "weightLinMom", "weightRPY", "weightRPYError", "weightAngMom"};
-    for (const char* k : vecKeys) { h.vectors[k] = std::vector<double>(p, p + 3); p += 3; }
-    h.vectors["weightDeltaJoint"] = std::vector<double>(p, p + 8); p += 8;
+    for (const char* k : vecKeys) { h.testSet(k, std::vector<double>(p, p + 3)); p += 3; }
+    h.testSet("weightDeltaJoint", std::vector<double>(p, p + 8)); p += 8;
     const char* tailKeys[] = {"weightThrottle", "weightInitialThrottle", "weightRegularizationJointPos", "throttleMin", "throttleMax"};
-    for (const char* k : tailKeys) h.scalars[k] = *p++;
-    h.scalars["useEstimatedThrust"] = useEst ? 1.0 : 0.0;
-    h.strings["jointsLambdaOption"] = constantLambda ? "constant" : "unfiltered";
+    for (const char* k : tailKeys) h.testSet(k, *p++);
+    h.testSet("useEstimatedThrust", useEst ? 1.0 : 0.0);
+    h.testSet("jointsLambdaOption", constantLambda ? "constant" : "unfiltered");
     std::vector<std::string> names;
     for (int i = 0; i < 8; ++i) names.push_back("joint_" + std::to_string(int(*p++)));
-    h.stringLists["controlledJoints"] = names;
-    if (dropKey) h.scalars.erase("weightThrottle");
+    h.testSet("controlledJoints", names);
+    if (dropKey) h.testErase("weightThrottle");
+    // the two trajectory groups as src/config/vs_mcp_config.xml:34-40 holds them: a file name each.  The stand-in
+    // TrajectoryManager takes the arrays registered under that name instead of opening a MAT file.
+    {
+        auto positionGroup = std::make_shared<YarpImplementation>(), alphaGroup = std::make_shared<YarpImplementation>();
+        positionGroup->testSet("trajectoryFile", "src/trajectories/minimumJerkTrajectory.mat");
+        alphaGroup->testSet("trajectoryFile", "src/trajectories/alphaGravity.mat");
+        h.setGroup("POSITION_TRAJECTORY", positionGroup);
+        h.setGroup("TRAJECTORY_MANAGER", alphaGroup);
+        TrajectoryManager::TestFile pos, alp;
+        pos.fps = posFps;
+        pos.tracks = {{"positionCoM", 3, std::vector<double>(posCoM, posCoM + 3 * nPos)},
+                      {"velocityCoM", 3, std::vector<double>(velCoM, velCoM + 3 * nPos)},
+                      {"RPY", 3, std::vector<double>(rpyTrack, rpyTrack + 3 * nPos)},
+                      {"RPYDot", 3, std::vector<double>(rpyDotTrack, rpyDotTrack + 3 * nPos)}};
+        alp.fps = alphaFps;
+        alp.tracks = {{"alphaGravity", 1, std::vector<double>(alphaTrack, alphaTrack + nAlpha)}};
+        TrajectoryManager::testFiles()["src/trajectories/minimumJerkTrajectory.mat"] = pos;
+        TrajectoryManager::testFiles()["src/trajectories/alphaGravity.mat"] = alp;
+    }
 
-    fake::QPInput qp;
-    qp.robot = std::make_shared<fake::Robot>();
-    qp.robotReference = distinct ? std::make_shared<fake::Robot>() : qp.robot;
-    for (int i = 0; i < 4; ++i) qp.throttleMPC(i) = *p++;
-    for (int i = 0; i < 4; ++i) qp.thrustDesMPC(i) = *p++;
-    for (int i = 0; i < 4; ++i) qp.thrustDotDesMPC(i) = *p++;
-    for (int i = 0; i < 4; ++i) qp.estimatedThrustDot(i) = *p++;
-    for (int i = 0; i < fake::NJ; ++i) qp.outputQPJointsPosition(i) = *p++;
-
-    auto position = std::make_shared<vsmpc_host::Trajectory>();
-    auto alpha = std::make_shared<vsmpc_host::Trajectory>();
-    const int desPos = int(1.0 / h.scalars["periodMPCLargeSteps"]);   // costsVSMPC.cpp:68
-    const int desAlpha = int(1.0 / h.scalars["periodMPC"]);            // systemDynamicsVSMPC.cpp:272
-    position->add("positionCoM", posCoM, nPos, 3, posFps, desPos);
-    position->add("velocityCoM", velCoM, nPos, 3, posFps, desPos);
-    position->add("RPY", rpyTrack, nPos, 3, posFps, desPos);
-    position->add("RPYDot", rpyDotTrack, nPos, 3, posFps, desPos);
-    alpha->add("alphaGravity", alphaTrack, nAlpha, 1, alphaFps, desAlpha);
+    QPInput qp;
+    qp.setRobot(std::make_shared<Robot>());
+    qp.setRobotReference(distinct ? std::make_shared<Robot>() : qp.getRobot());
+    auto take = [&](int n) { Eigen::VectorXd v(n); for (int i = 0; i < n; ++i) v(i) = *p++; return v; };
+    qp.setThrottleMPC(take(4));
+    qp.setThrustDesMPC(take(4));
+    qp.setThrustDotDesMPC(take(4));
+    qp.setEstimatedThrustDot(take(4));
+    qp.setOutputQPJointsPosition(take(Robot::kJoints));
 
     auto loadTick = [&]() {
-        qp.robot->load(p); p += fake::ROBOT_BLOCK;
-        if (distinct) { qp.robotReference->load(p); p += fake::ROBOT_BLOCK; }
-        for (int i = 0; i < 4; ++i) qp.estimatedThrustDot(i) = *p++;
+        qp.getRobot()->testLoad(p); p += Robot::kBlock;
+        if (distinct) { qp.getRobotReference()->testLoad(p); p += Robot::kBlock; }
+        qp.setEstimatedThrustDot(take(4));
     };
     loadTick();   // configure-time state
-    vsmpc_host::VariableSamplingMPCT<fake::QPInput> mpc;
-    mpc.setTrajectories(position, alpha);
-    if (!mpc.configure(h, qp)) {
+    VariableSamplingMPCGpu mpc;
+    const bool latency = argc > 4 && !std::strcmp(argv[3], "latency");
+    const bool twoCall = (argc > 3 && !std::strcmp(argv[3], "two-call")) || (argc > 5 && !std::strcmp(argv[5], "two-call"));
+    if (twoCall) mpc.setFusedTick(false);
+    std::weak_ptr<BipedalLocomotion::ParametersHandler::IParametersHandler> weakHandler = handler;
+    if (!configureVariableSamplingMPCGpu(mpc, weakHandler, qp)) {
         std::printf("configure failed: %s\n", mpc.getLastMessage().c_str());
         return dropKey ? 10 : 4;
+    }
+    if (latency) {
+        const int total = std::atoi(argv[4]);
+        const double* firstTick = p;
+        std::vector<double> us;
+        us.reserve(size_t(total));
+        Eigen::VectorXd u4(4), q(Robot::kJoints);
+        int solved = 0;
+        for (int k = 0; k < total + 50; ++k) {
+            if (k % nTicks == 0) p = firstTick;   // cycle through the scenario's provider states
+            loadTick();
+            const auto t0 = std::chrono::steady_clock::now();
+            const bool ok = mpc.update(qp);
+            mpc.solveMPC();
+            const auto t1 = std::chrono::steady_clock::now();
+            if (!ok) return 6;
+            if (k >= 50) {   // first ticks: code object load, clocks
+                us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+                solved += mpc.getQPProblemStatus() == VSMPC_STATUS_SOLVED;
+            }
+            mpc.getThrottleReference(u4); qp.setThrottleMPC(u4);
+            mpc.getThrustReference(u4); qp.setThrustDesMPC(u4);
+            mpc.getThrustDotReference(u4); qp.setThrustDotDesMPC(u4);
+            mpc.getJointsReferencePosition(q); qp.setOutputQPJointsPosition(q);
+        }
+        std::sort(us.begin(), us.end());
+        double mean = 0.0;
+        for (double v : us) mean += v;
+        std::printf("{\"ticks\": %d, \"solved\": %d, \"p50_us\": %.2f, \"p99_us\": %.2f, \"mean_us\": %.2f, \"form\": \"%s\"}\n", total,
+                    solved, us[us.size() / 2], us[size_t(double(us.size()) * 0.99)], mean / double(us.size()),
+                    twoCall ? "update: vsmpc_kinematics_batch, solveMPC: vsmpc_solve_batch" : "solveMPC: vsmpc_tick");
+        return 0;
     }
     FILE* o = std::fopen(argv[2], "wb");
     if (!o) return 5;
     const int nIn = mpc.tickMachine().nIn();
-    std::vector<double> row(size_t(nIn) + 1 + 12 + fake::NJ + 3 + 3 + 1 + 6);
+    std::vector<double> row(size_t(nIn) + 1 + 12 + Robot::kJoints + 3 + 3 + 1 + 6);
+    Eigen::VectorXd t4(4), q23(Robot::kJoints);
     for (int k = 0; k < nTicks; ++k) {
         loadTick();
-        if (!mpc.update(qp)) { std::printf("update failed at tick %d: %d\n", k, mpc.getLastError()); return 6; }
-        mpc.solveMPC();
+        if (k % 2 == 0) {   // alternate between the snippet's tick function and the bare calls
+            if (!tickVariableSamplingMPCGpu(mpc, qp, q23, t4)) { std::printf("tick %d failed: %d\n", k, mpc.getLastError()); return 6; }
+        } else {
+            if (!mpc.update(qp)) { std::printf("update failed at tick %d: %d\n", k, mpc.getLastError()); return 6; }
+            mpc.solveMPC();
+        }
         double* r = row.data();
-        for (int i = 0; i < nIn; ++i) *r++ = mpc.tickMachine().record()[i];
+        for (int i = 0; i < nIn; ++i) *r++ = mpc.tickMachine().record()[i];   // the record that was solved
         *r++ = mpc.getQPProblemStatus();
-        fake::Vec t4{std::vector<double>(4)}, q23{std::vector<double>(fake::NJ)};
         if (!mpc.getThrustReference(t4)) return 7;
         for (int i = 0; i < 4; ++i) *r++ = t4(i);
         mpc.getThrustDotReference(t4);
         for (int i = 0; i < 4; ++i) *r++ = t4(i);
         mpc.getThrottleReference(t4);
         for (int i = 0; i < 4; ++i) *r++ = t4(i);
-        fake::Vec wrongSize{std::vector<double>(5)};
+        Eigen::VectorXd wrongSize(5);
         if (mpc.getThrottleReference(wrongSize)) return 8;   // size-checked like the reference
         mpc.getJointsReferencePosition(q23);
-        for (int i = 0; i < fake::NJ; ++i) *r++ = q23(i);
-        for (int i = 0; i < 3; ++i) *r++ = qp.posCoMReference(i);
-        for (int i = 0; i < 3; ++i) *r++ = qp.rpyReference(i);
-        *r++ = qp.alphaGravity;
-        for (int i = 0; i < 6; ++i) *r++ = qp.momentumReference(i);
+        for (int i = 0; i < Robot::kJoints; ++i) *r++ = q23(i);
+        for (int i = 0; i < 3; ++i) *r++ = qp.getPosCoMReference()(i);
+        for (int i = 0; i < 3; ++i) *r++ = qp.getRPYReference()(i);
+        *r++ = qp.getAlphaGravity();
+        for (int i = 0; i < 6; ++i) *r++ = qp.getMomentumReference()(i);
         std::fwrite(row.data(), sizeof(double), row.size(), o);
         // harness feedback (src/variable_sampling_mpc.py:124-135)
-        mpc.getThrottleReference(qp.throttleMPC);
-        mpc.getThrustReference(qp.thrustDesMPC);
-        mpc.getThrustDotReference(qp.thrustDotDesMPC);
-        mpc.getJointsReferencePosition(qp.outputQPJointsPosition);
+        mpc.getThrottleReference(t4); qp.setThrottleMPC(t4);
+        mpc.getThrustReference(t4); qp.setThrustDesMPC(t4);
+        mpc.getThrustDotReference(t4); qp.setThrustDotDesMPC(t4);
+        qp.setOutputQPJointsPosition(q23);
     }
     std::fclose(o);
     return 0;

@@ -24,16 +24,43 @@ def test_header_compiles_and_links(tmp_path, solver_mod):
     build_driver(tmp_path, solver_mod)
 
 
-def test_reference_surface_template_compiles_and_links(tmp_path, solver_mod):
-    """include/VariableSamplingMPC.hpp's VariableSamplingMPCT against provider classes with the members of Robot.h /
-    QPInput.h / IParametersHandler (tests/cpp/reference_surface_driver.cpp); run on the GPU by
+def _refstub_cmd(src, out, extra=()):
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    return ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(cpp, "refstub"), "-I", cpp,
+            *extra, src, "-o", out]
+
+
+def test_reference_side_binding_compiles_against_the_reference_signatures(tmp_path, solver_mod):
+    """vsmpc_host::VariableSamplingMPCT<QPInput, TrajectoryManager> -- INTEGRATION.md section 2, through
+    tests/cpp/integration_snippet.cpp verbatim -- builds and links against signature-exact stand-ins of the reference's
+    QPInput.h / Robot.h / TrajectoryManager.h / IParametersHandler (tests/cpp/refstub/); run on the GPU by
     tests/test_gpu_reference_surface.py."""
     exe = str(tmp_path / "reference_surface_driver")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "reference_surface_driver.cpp"), "-o", exe,
-           "-L", PKG_DIR, "-lvsmpc", f"-Wl,-rpath,{PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = _refstub_cmd(os.path.join(ROOT, "tests", "cpp", "reference_surface_driver.cpp"), exe) + [
+        "-L", PKG_DIR, "-lvsmpc", f"-Wl,-rpath,{PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+@pytest.mark.parametrize("bad, needle", [
+    # what round 3's header did, one by one: each must be a COMPILE error against the stand-ins, i.e. the stand-ins are as
+    # strict as the reference's declarations (QPInput.h:41,45,67; TrajectoryManager.h:104)
+    ("double v[3] = {0, 0, 0}; qp.setPosCoMReference(v);", "setPosCoMReference"),
+    ("double v[6] = {0}; qp.setMomentumReference(v);", "setMomentumReference"),
+    ("const double* p = tm.getCurrentValue(\"positionCoM\"); (void)p;", "getCurrentValue"),
+    ("bool b = tm.has(\"RPY\"); (void)b;", "has"),
+    ("mpc.configure(*weak.lock(), qp); using H = decltype(weak); H w2 = weak; vsmpc_host::MPCParameters p; vsmpc_host::readParameters(w2, p);", "getParameter"),
+])
+def test_refstub_rejects_what_the_reference_would_reject(tmp_path, bad, needle):
+    src = tmp_path / "neg.cpp"
+    src.write_text('''#include "integration_snippet.cpp"
+int main() {
+    QPInput qp; TrajectoryManager tm; VariableSamplingMPCGpu mpc;
+    std::weak_ptr<BipedalLocomotion::ParametersHandler::IParametersHandler> weak;
+    (void)qp; (void)tm; (void)mpc; (void)weak;
+    ''' + bad + "\n    return 0;\n}\n")
+    res = subprocess.run(_refstub_cmd(str(src), str(tmp_path / "neg.o"), extra=("-c",)), capture_output=True, text=True)
+    assert res.returncode != 0 and needle in res.stderr, res.stderr[-2000:]
 
 
 def test_tick_state_machine_semantics(tmp_path):

@@ -409,6 +409,34 @@ def test_kinematics_terms_match_oracle(mpc, ref, synth, layout):
     assert (st == layout.STATUS_SOLVED).all()
 
 
+@pytest.mark.parametrize("B", [1, 5, 37])
+def test_tick_is_kinematics_then_solve_in_one_submission(mpc, synth, layout, B):
+    """vsmpc_tick (the drop-in tick: update()'s kinematics terms + solveMPC() in one submission) == vsmpc_kinematics_batch
+    followed by vsmpc_solve_batch, bit for bit -- through the mapped staging buffer (B <= 8) and through device buffers."""
+    rng = np.random.default_rng(100 + B)
+    kin = rng.normal(size=(B, layout.KIN_SIZE))
+    for b in range(B):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        kin[b, layout.KIN_WRB:layout.KIN_WRB + 9] = (q * np.sign(np.linalg.det(q))).reshape(-1)
+        kin[b, layout.KIN_THRUST:layout.KIN_THRUST + 4] = rng.uniform(20, 220, size=4)
+        a = rng.normal(size=(6, 6))
+        kin[b, layout.KIN_MB:layout.KIN_MB + 36] = (a @ a.T + 6 * np.eye(6)).reshape(-1)
+    recs = synth.make_batch(layout.paper_config(), B, workload="takeoff")
+    two = recs.copy()
+    mpc.kinematics(kin, two)
+    x2, fm2, st2, it2 = mpc.solve(two)
+    one = recs.copy()
+    one[:, layout.IN_LLIN:layout.IN_LLIN + 48] = np.nan          # whatever the caller left there is overwritten
+    one[:, layout.IN_INERTIA:layout.IN_INERTIA + 9] = np.nan
+    x1, fm1, st1, it1 = mpc.tick(kin, one)
+    np.testing.assert_array_equal(one, two)                       # the completed record comes back
+    np.testing.assert_array_equal(x1, x2)
+    np.testing.assert_array_equal(fm1, fm2)
+    np.testing.assert_array_equal(st1, st2)
+    np.testing.assert_array_equal(it1, it2)
+    assert (st1 == layout.STATUS_SOLVED).all()
+
+
 def test_kinematics_options_match_oracle(solver_mod, ref, layout):
     """vsmpc_set_kinematics_options: Lambda_ang columns selected by (name-derived) robot joint index
     (systemDynamicsVSMPC.cpp:57-66,202-205) and jointsLambdaOption 'constant' (:186-200,329-337)."""

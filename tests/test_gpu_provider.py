@@ -105,3 +105,27 @@ def test_provider_feeds_the_solve_without_the_host(solver_mod, synth, layout, re
             assert relerr(x[b], xr) < 1e-8
     finally:
         m.close()
+
+
+def test_provider_refuses_constant_lambda(solver_mod, synth, layout):
+    """jointsLambdaOption 'constant' re-reads the Jacobian slots of the kinematics record as configure-time quantities the
+    provider does not deliver: patching records through the provider with that option set is refused, not silently wrong."""
+    RT = importlib.import_module(PKG + ".robot_tree")
+    tree = RT.default_tree()
+    cfg = layout.paper_config()
+    rng = np.random.default_rng(5)
+    sts = random_states(rng, 2)
+    packed = np.stack([RT.pack_state(s["p_base"], s["R_base"], s["v_base"], s["w_base"], s["q"], s["qd"], s["thrust"]) for s in sts])
+    recs = synth.make_batch(cfg, 2, workload="hover")
+    m = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=4)
+    try:
+        m.set_kinematics_options(None, True)
+        before = recs.copy()
+        with pytest.raises(Exception, match="unsupported"):
+            m.provider(tree, packed, recs)
+        np.testing.assert_array_equal(recs, before)
+        m.provider(tree, packed)                       # the Robot-level outputs alone do not depend on the option
+        m.set_kinematics_options(None, False)
+        m.provider(tree, packed, recs)
+    finally:
+        m.close()

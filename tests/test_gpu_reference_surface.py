@@ -2,12 +2,15 @@
 
 include/VariableSamplingMPC.hpp holds ONE implementation of the packer + tick state machine (TickMachine) and the
 reference-signature class template VariableSamplingMPCT (configure(parametersHandler, qpInput) / update(qpInput) /
-solveMPC / getters, MPCPyBindings.cpp:22-90).  It is driven here three ways through the SAME provider states
-(tests/fake_provider.py): as C++ against fake classes with the members of Robot.h / QPInput.h / IParametersHandler
-(tests/cpp/reference_surface_driver.cpp), through the pybind module bindingsMPC with Python provider objects, and -- the
-checker -- the Python twin reference_api, whose records tests/test_gpu_reference_api.py pins against the model written
-from the reference's plugins (tests/tick_model.py).  Variants: getRobot() != getRobotReference(), controlled joints
-selected by NAME at other positions than 3..10, jointsLambdaOption 'constant', a non-zero RPY / RPYDot track."""
+solveMPC / getters, MPCPyBindings.cpp:22-90).  tests/cpp/reference_surface_driver.cpp instantiates it as
+VariableSamplingMPCT<QPInput, TrajectoryManager> over SIGNATURE-EXACT stand-ins of the reference's headers
+(tests/cpp/refstub/) through the INTEGRATION.md snippet verbatim, and is checked here
+  * directly against the model written from the reference's plugins (tests/tick_model.py) with the oracle's kinematics
+    terms (test_compiled_surface_matches_the_reference_tick_model: the shipped configuration);
+  * against the pybind module bindingsMPC and the Python twin reference_api driven through the SAME provider states
+    (tests/fake_provider.py) in the variants the tick model does not cover: getRobot() != getRobotReference(), controlled
+    joints selected by NAME at other positions than 3..10, jointsLambdaOption 'constant', a non-zero RPY / RPYDot track
+    (the twin itself is pinned against the tick model by tests/test_gpu_reference_api.py)."""
 import importlib
 import json
 import os
@@ -17,6 +20,7 @@ import numpy as np
 import pytest
 
 import fake_provider as fp
+import tick_model as tm
 from conftest import PKG, ROOT, relerr
 
 pytestmark = pytest.mark.gpu
@@ -28,8 +32,9 @@ N_TICKS = 45
 @pytest.fixture(scope="module")
 def driver(tmp_path_factory, solver_mod):
     exe = str(tmp_path_factory.mktemp("refsurf") / "reference_surface_driver")
-    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), DRV, "-o", exe,
-           "-L", PKG_DIR, "-lvsmpc", f"-Wl,-rpath,{PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib"]
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(cpp, "refstub"), "-I", cpp, DRV,
+           "-o", exe, "-L", PKG_DIR, "-lvsmpc", f"-Wl,-rpath,{PKG_DIR}", "-Wl,-rpath,/opt/rocm/lib"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     return exe
@@ -58,9 +63,9 @@ def drive(mpc, qp, sc, get_record, n_in):
     for k in range(1, sc.n_ticks + 1):
         qp.setEstimatedThrustDot(sc.load(k))
         assert mpc.update(qp)
-        rec = np.array(get_record(mpc), dtype=float)
-        assert rec.shape == (n_in,)
         assert mpc.solveMPC()
+        rec = np.array(get_record(mpc), dtype=float)          # the record that was solved (fused tick: complete after solveMPC)
+        assert rec.shape == (n_in,)
         rows.append(np.concatenate([rec, [mpc.getQPProblemStatus()], mpc.getThrustReference(), mpc.getThrustDotReference(),
                                     mpc.getThrottleReference(), mpc.getJointsReferencePosition(), qp.getPosCoMReference(),
                                     qp.getRPYReference(), [qp.getAlphaGravity()], qp.getMomentumReference()]))
@@ -138,6 +143,103 @@ def test_compiled_surface_matches_the_python_twin(driver, pinned, variant, tmp_p
         assert set(np.nonzero(moved)[0]) == set(selector)
     if variant == "rpy-track":
         assert np.abs(cpp[:, layout.IN_XREF + 9:layout.IN_XREF + 12]).max() > 0      # h_ang reference = I_G W RPYDot
+
+
+def _kin_record(robot, layout):
+    k = np.zeros(layout.KIN_SIZE)
+    k[layout.KIN_WRB:layout.KIN_WRB + 9] = robot.getBaseRotation().reshape(-1)
+    k[layout.KIN_THRUST:layout.KIN_THRUST + 4] = robot.T
+    k[layout.KIN_AXES:layout.KIN_AXES + 12] = robot.axes.reshape(-1)
+    k[layout.KIN_ARMS:layout.KIN_ARMS + 12] = robot.arms.reshape(-1)
+    k[layout.KIN_JREL:layout.KIN_JREL + 276] = np.stack([j[3:6] for j in robot.jrel]).reshape(-1)
+    k[layout.KIN_JFRAME:layout.KIN_JFRAME + 276] = np.stack([j[0:3, 6:29] for j in robot.jframe]).reshape(-1)
+    k[layout.KIN_JCOM:layout.KIN_JCOM + 69] = robot.jcom[0:3, 6:29].reshape(-1)
+    k[layout.KIN_MB:layout.KIN_MB + 36] = robot.M[0:6, 0:6].reshape(-1)
+    k[layout.KIN_R:layout.KIN_R + 3] = robot.p - robot.base
+    return k
+
+
+@pytest.mark.parametrize("mode", ["fused", "two-call"])
+def test_compiled_surface_matches_the_reference_tick_model(driver, pinned, mode, tmp_path, layout, solver_mod, ref):
+    """The C++ instantiation over the reference-typed stand-ins against the model written from the reference's plugins
+    (tests/tick_model.py; kinematics terms from the oracle) -- no product module in the checker.  Every record the binding
+    builds, tick by tick, and its outputs = the C-ABI's outputs for that record.  Both tick forms: one vsmpc_tick submission
+    per tick (default) and the update() / solveMPC() pair with a kinematics round trip in update()."""
+    consts, traj = pinned
+    sc = fp.Scenario(n_ticks=N_TICKS, seed=17)
+    selector = list(range(3, 11))
+    (tmp_path / "scenario.bin").write_bytes(sc.serialise(consts, traj, selector).tobytes())
+    args = [driver, str(tmp_path / "scenario.bin"), str(tmp_path / "out.bin")] + (["two-call"] if mode == "two-call" else [])
+    res = subprocess.run(args, capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    cfg = layout.paper_config()
+    n_in = cfg.n_in
+    cpp = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.float64).reshape(N_TICKS, -1)
+
+    robot = sc.robot
+    q = sc.initial_qp
+    fb = dict(throttle=q["throttle"].copy(), thrustDes=q["thrustDes"].copy(), thrustDotDes=q["thrustDotDes"].copy(),
+              joints=q["joints"].copy())
+
+    def plant_arrays(est_td, q_ref0):
+        s = np.zeros(layout.PLANT_STATE); p = np.zeros(layout.PLANT_PARAMS)
+        s[layout.PS_P:layout.PS_P + 3] = robot.p
+        s[layout.PS_HLIN:layout.PS_HLIN + 3] = robot.h[0:3]
+        s[layout.PS_RPY:layout.PS_RPY + 3] = robot.rpy
+        s[layout.PS_HANG:layout.PS_HANG + 3] = robot.h[3:6]
+        s[layout.PS_T:layout.PS_T + 4] = robot.T
+        s[layout.PS_TD:layout.PS_TD + 4] = est_td
+        s[layout.PS_Q:layout.PS_Q + 8] = fb["joints"][3:11]
+        s[layout.PS_U:layout.PS_U + 4] = fb["throttle"]
+        s[layout.PS_TDES:layout.PS_TDES + 4] = fb["thrustDes"]
+        s[layout.PS_TDDES:layout.PS_TDDES + 4] = fb["thrustDotDes"]
+        p[layout.PP_MASS] = robot.mass
+        p[layout.PP_QREF0:layout.PP_QREF0 + 8] = q_ref0
+        return s, p
+
+    est0 = sc.load(0)
+    q_ref0 = robot.q[3:11].copy()
+    s0, p0 = plant_arrays(est0, q_ref0)
+    model = tm.ReferenceTickModel(cfg, s0, p0, traj["positionCoM"], traj["velocityCoM"], traj["alphaGravity"])
+    raw = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=1)
+    try:
+        for k in range(N_TICKS):
+            est = sc.load(k + 1)
+            rec = cpp[k, :n_in]
+            s, p = plant_arrays(est, q_ref0)
+            kin = np.zeros(n_in)
+            R = robot.getBaseRotation()
+            kin[layout.IN_MASS] = float(np.float32(robot.mass))
+            kin[layout.IN_WRB:layout.IN_WRB + 9] = R.reshape(-1)
+            kin[layout.IN_OMEGA:layout.IN_OMEGA + 3] = R.T @ robot.omega_world
+            kin[layout.IN_GRAV:layout.IN_GRAV + 3] = [0.0, 0.0, -9.81]
+            kin[layout.IN_AMOM:layout.IN_AMOM + 24] = robot.amom_body.reshape(-1)
+            l1, l2, ig = ref.kinematics_terms(_kin_record(robot, layout))
+            kin[layout.IN_LLIN:layout.IN_LLIN + 24] = l1.reshape(-1)
+            kin[layout.IN_LANG:layout.IN_LANG + 24] = l2.reshape(-1)
+            kin[layout.IN_INERTIA:layout.IN_INERTIA + 9] = ig.reshape(-1)
+            kin[layout.IN_T0:layout.IN_T0 + 4] = robot.T
+            kin[layout.IN_TD0:layout.IN_TD0 + 4] = est
+            fields = model.update(s)
+            exp = tm.record_from_tick(cfg, fields, kin)
+            assert relerr(rec, exp) < 1e-12, (k, int(np.abs(rec - exp).argmax()))
+            assert rec[layout.IN_HOLD] == (0.0 if k % 20 == 19 else 1.0)
+            x, fm, st, it = raw.solve(rec[None, :])
+            o = n_in
+            assert cpp[k, o] == st[0] == layout.STATUS_SOLVED
+            np.testing.assert_array_equal(cpp[k, o + 1:o + 5], fm[0, 16:20])       # thrust reference
+            np.testing.assert_array_equal(cpp[k, o + 5:o + 9], fm[0, 20:24])       # thrust-rate reference
+            np.testing.assert_array_equal(cpp[k, o + 9:o + 13], fm[0, 12:16])      # throttle reference
+            model.consume(fm[0], st[0])
+            np.testing.assert_allclose(cpp[k, o + 13 + 3:o + 13 + 11], model.m_jointsPositionReference, rtol=0, atol=1e-15)
+            # what the binding wrote back into the QPInput (costsVSMPC.cpp:155-160, systemDynamicsVSMPC.cpp:310)
+            assert cpp[k, o + 36 + 6] == fields["alpha"]
+            fb = dict(throttle=cpp[k, o + 9:o + 13].copy(), thrustDes=cpp[k, o + 1:o + 5].copy(),
+                      thrustDotDes=cpp[k, o + 5:o + 9].copy(), joints=cpp[k, o + 13:o + 36].copy())
+    finally:
+        raw.close()
+        sc.load(0)
+
 
 
 def test_compiled_surface_reports_a_missing_key(driver, pinned, tmp_path):
