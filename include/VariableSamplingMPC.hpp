@@ -377,6 +377,9 @@ public:
             m_axesInit = robot.jetAxes;
             m_armsInit = robot.jetArms;
         }
+        m_x.assign(m_nVar, 0.0);          // per-tick scratch: allocated here, never in assemble() / solve()
+        m_kin.assign(VSMPC_KIN_SIZE, 0.0);
+        m_kinPending = false;
         m_window.assign(size_t(12) * m_nRef, 0.0);
         double col[12];
         rc = referenceColumn(robot, col);
@@ -391,9 +394,6 @@ public:
         m_thrustDot.assign(4, 0.0);
         m_throttle.assign(4, 0.0);
         m_finalState.assign(VSMPC_N_STATES, 0.0);
-        m_x.assign(m_nVar, 0.0);          // per-tick scratch: allocated here, never in assemble() / solve()
-        m_kin.assign(VSMPC_KIN_SIZE, 0.0);
-        m_kinPending = false;
         m_status = 0;
         return assemble(robot, ref, qp, wb);   // IMPCProblem.cpp:80-132 evaluates every plugin once
     }

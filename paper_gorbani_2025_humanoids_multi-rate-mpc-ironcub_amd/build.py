@@ -1,4 +1,4 @@
-"""Builds the HIP library in-tree: csrc/*.hip -> libvsmpc.so (gfx950 only).
+"""Builds the HIP library in-tree: csrc/*.hip -> build/*.o -> libvsmpc.so (gfx950 only).
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
 git-ignored but travels with the tree to the GPU box.
@@ -56,6 +56,32 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the vsmpc HIP library cannot be built")
 
 
+OBJ_DIR = os.path.join(HERE, "build")
+
+
+def _units():
+    """(object name, source, extra flags): vsmpc_kernels.hip is compiled once for its common part and twice per horizon
+    (production / diagnostic instantiations, see the note on translation units in the file), everything else once."""
+    units = [("kernels_common", "vsmpc_kernels.hip", ["-DVS_TU_COMMON"])]
+    for n, ns, hc in horizons():
+        for st in (0, 1):
+            units.append((f"kernels_{n}_{ns}_{hc}_{'diag' if st else 'prod'}", "vsmpc_kernels.hip",
+                          [f"-DVS_TU_HORIZON={n},{ns},{hc}", f"-DVS_TU_STAMPS={st}"]))
+    for src in SOURCES:
+        if src != "vsmpc_kernels.hip":
+            units.append((os.path.splitext(src)[0], src, []))
+    return units
+
+
+def _deps(src):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def _extra_flags():
+    """VSMPC_HIPCC_FLAGS: measurement builds (tools/exp_build.sh), e.g. -DVS_DIAG_SPLIT"""
+    return os.environ.get("VSMPC_HIPCC_FLAGS", "").split()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -64,19 +90,54 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """Objects under build/ (git-ignored), one hipcc process each, `jobs` at a time (default: the CPUs of the machine, at
+    most 8); an object is rebuilt when its source, a header or this file is newer, or when its flags changed."""
+    from concurrent.futures import ThreadPoolExecutor
     changed = write_horizons_def()
     if not force and not changed and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + _extra_flags()
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    todo, objs = [], []
+    for name, src, flags in _units():
+        obj = os.path.join(OBJ_DIR, name + ".o")
+        stamp = obj + ".flags"
+        cmd = base + flags + [os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        flagtext = " ".join(cmd)
+        fresh = (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flagtext
+                 and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)))
+        if not fresh:
+            todo.append((cmd, stamp, flagtext))
+
+    def run(item):
+        cmd, stamp, flagtext = item
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode == 0:
+            with open(stamp, "w") as f:
+                f.write(flagtext)
+        return cmd, res
+
+    jobs = jobs or int(os.environ.get("VSMPC_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        results = list(pool.map(run, todo))
+    for cmd, res in results:
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+        if verbose:
+            print(res.stderr)
+    keep = {os.path.basename(o) for o in objs}
+    for f in os.listdir(OBJ_DIR):           # objects of horizons that left the table
+        if f.endswith(".o") and f not in keep:
+            os.remove(os.path.join(OBJ_DIR, f))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", LIB_PATH] + objs
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    if verbose:
-        print(res.stderr)
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 

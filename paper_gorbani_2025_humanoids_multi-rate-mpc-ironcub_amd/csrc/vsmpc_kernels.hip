@@ -2884,6 +2884,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
 #undef VS_TOC
 }
 
+#if !defined(VS_TU_HORIZON)
 // ------------------------------------------------------------------------------------------------
 // kinematics-derived inputs (vsmpc_kinematics_batch): Lambda_lin,B, Lambda_ang,B, I_G per instance.
 // HBM-bound (5.6 KB in, 0.46 KB out per instance): one wavefront per instance stages the record in LDS with
@@ -2988,21 +2989,33 @@ hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, cons
     return hipGetLastError();
 }
 
+#endif  // !VS_TU_HORIZON (common part: the non-template kernels)
+
 // ------------------------------------------------------------------------------------------------
 // launchers.  The kernels are straight-line template instantiations over Dims<nIter, nIterSmall, controlHorizon>; the
 // table of instantiated horizons is csrc/vsmpc_horizons.def (one X(...) line per horizon, generated by build.py from
 // the list of horizons to support).  Variant ids are 1-based positions in that table.
+//
+// Translation units.  Every horizon is ~10 instantiations of a 30 k-instruction kernel, and a monolithic build compiled
+// them one after the other (4.5 minutes).  build.py therefore compiles this file several times, in parallel:
+//   -DVS_TU_COMMON                         the non-template kernels, the horizon table and the dispatchers
+//   -DVS_TU_HORIZON=N,NS,HC -DVS_TU_STAMPS=0|1   the production (0) or diagnostic (1) solve kernels of ONE horizon
+//                                          (+ its linearise kernel in the production unit), as explicit instantiations of
+//                                          launch_solve_dims / launch_linearize_dims, which the dispatchers only declare
+// Without either macro the file is one monolithic unit, as before.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAX_DEVICES = 64;
 
-// condensing form of a handle: 0 = the default of the horizon (structured where Dims::STRUCT_P1), 1 = structured,
-// 2 = SYRK (vsmpc_set_kernel_form).  VSMPC_FORM=structured|syrk is what a new handle starts with, for measurements of
-// unmodified programs.
-int initial_kernel_form() {
-    const char* v = getenv("VSMPC_FORM");
-    return (v != nullptr && v[0] == 's' && v[1] == 't') ? 1 : (v != nullptr && v[0] == 's' && v[1] == 'y') ? 2 : 0;
-}
+template <int N, int NS, int HC, bool STAMPS>
+hipError_t launch_solve_dims(int form, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+                             int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
+                             hipStream_t stream);
+template <int N, int NS, int HC>
+hipError_t launch_linearize_dims(const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj, double* Bt,
+                                 double* c, hipStream_t stream);
 
+#if !defined(VS_TU_COMMON)
+// ---- per-horizon part
 template <class D, bool STAMPS, int FORM, bool PLDS = false>
 static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
                                  int* d_status, int* d_iters, double* dbgM, double* dbgL,
@@ -3023,10 +3036,11 @@ static hipError_t launch_solve_f(int dev, const DevCfg& cfg, const double* d_in,
     return hipGetLastError();
 }
 
-template <class D, bool STAMPS>
-static hipError_t launch_solve_t(int form, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
-                                 int* d_status, int* d_iters, double* dbgM, double* dbgL,
-                                 unsigned long long* stamps, hipStream_t stream) {
+template <int N, int NS, int HC, bool STAMPS>
+hipError_t launch_solve_dims(int form, const DevCfg& cfg, const double* d_in, int batch, double* d_x, double* d_fm,
+                             int* d_status, int* d_iters, double* dbgM, double* dbgL, unsigned long long* stamps,
+                             hipStream_t stream) {
+    using D = Dims<N, NS, HC>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -3058,11 +3072,42 @@ static hipError_t launch_solve_t(int form, const DevCfg& cfg, const double* d_in
                                             stream);
 }
 
-template <class D>
-static hipError_t launch_linearize_t(const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj,
-                                     double* Bt, double* c, hipStream_t stream) {
-    hipLaunchKernelGGL(linearize_kernel<D>, dim3(batch), dim3(256), 0, stream, cfg, d_in, A, Bj, Bt, c);
+template <int N, int NS, int HC>
+hipError_t launch_linearize_dims(const DevCfg& cfg, const double* d_in, int batch, double* A, double* Bj, double* Bt,
+                                 double* c, hipStream_t stream) {
+    hipLaunchKernelGGL((linearize_kernel<Dims<N, NS, HC>>), dim3(batch), dim3(256), 0, stream, cfg, d_in, A, Bj, Bt, c);
     return hipGetLastError();
+}
+
+#define VS_INSTANTIATE_SOLVE(N, NS, HC, ST)                                                                              \
+    template hipError_t launch_solve_dims<N, NS, HC, ST>(int, const DevCfg&, const double*, int, double*, double*, int*, \
+                                                         int*, double*, double*, unsigned long long*, hipStream_t);
+#define VS_INSTANTIATE_LIN(N, NS, HC)                                                                                   \
+    template hipError_t launch_linearize_dims<N, NS, HC>(const DevCfg&, const double*, int, double*, double*, double*, \
+                                                         double*, hipStream_t);
+#if defined(VS_TU_HORIZON)
+#define VS_TU_APPLY(M, ...) M(__VA_ARGS__)
+#if VS_TU_STAMPS
+VS_TU_APPLY(VS_INSTANTIATE_SOLVE, VS_TU_HORIZON, true)
+#else
+VS_TU_APPLY(VS_INSTANTIATE_SOLVE, VS_TU_HORIZON, false)
+VS_TU_APPLY(VS_INSTANTIATE_LIN, VS_TU_HORIZON)
+#endif
+#else   // monolithic unit: every horizon of the table
+#define X(N, NS, HC) VS_INSTANTIATE_SOLVE(N, NS, HC, true) VS_INSTANTIATE_SOLVE(N, NS, HC, false) VS_INSTANTIATE_LIN(N, NS, HC)
+#include "vsmpc_horizons.def"
+#undef X
+#endif
+#endif  // per-horizon part
+
+#if !defined(VS_TU_HORIZON)
+// ---- common part
+// condensing form of a handle: 0 = the default of the horizon (structured where Dims::STRUCT_P1), 1 = structured,
+// 2 = SYRK (vsmpc_set_kernel_form).  VSMPC_FORM=structured|syrk is what a new handle starts with, for measurements of
+// unmodified programs.
+int initial_kernel_form() {
+    const char* v = getenv("VSMPC_FORM");
+    return (v != nullptr && v[0] == 's' && v[1] == 't') ? 1 : (v != nullptr && v[0] == 's' && v[1] == 'y') ? 2 : 0;
 }
 
 struct HorizonEntry {
@@ -3120,10 +3165,10 @@ hipError_t launch_solve(int variant, int form, const DevCfg& cfg, const double* 
 #define X(N, NS, HC)                                                                                                  \
     if (variant == ++id) {                                                                                            \
         if (stamps != nullptr || dbgM != nullptr || dbgL != nullptr)                                                  \
-            return launch_solve_t<Dims<N, NS, HC>, true>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,  \
-                                                         stamps, stream);                                             \
-        return launch_solve_t<Dims<N, NS, HC>, false>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,     \
-                                                      nullptr, stream);                                               \
+            return launch_solve_dims<N, NS, HC, true>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,   \
+                                                      stamps, stream);                                                \
+        return launch_solve_dims<N, NS, HC, false>(form, cfg, d_in, batch, d_x, d_fm, d_status, d_iters, dbgM, dbgL,      \
+                                                   nullptr, stream);                                                  \
     }
 #include "vsmpc_horizons.def"
 #undef X
@@ -3134,10 +3179,11 @@ hipError_t launch_linearize(int variant, const DevCfg& cfg, const double* d_in, 
                             double* Bt, double* c, hipStream_t stream) {
     int id = 0;
 #define X(N, NS, HC) \
-    if (variant == ++id) return launch_linearize_t<Dims<N, NS, HC>>(cfg, d_in, batch, A, Bj, Bt, c, stream);
+    if (variant == ++id) return launch_linearize_dims<N, NS, HC>(cfg, d_in, batch, A, Bj, Bt, c, stream);
 #include "vsmpc_horizons.def"
 #undef X
     return hipErrorInvalidValue;
 }
+#endif  // common part
 
 }  // namespace vsmpc
