@@ -7,14 +7,18 @@
  * the hardware gain: the same inputs, the same algorithm, CPU cores instead of the GPU.
  *
  *   linearise   vso_linearize (vsmpc_oracle.c; systemDynamicsVSMPC.cpp:79-103,288-319,384-429)
+ *   reduce      every joint block enters the dynamics through [Lambda_lin; Lambda_ang] (6 x 8, the same for all blocks,
+ *               constraintsVSMPC.cpp:85-103): Householder QR of (Lambda W^-1/2)^T, W the joint weights (costsVSMPC.cpp:
+ *               375-381,564-591) -> 6 unknowns y per block with input matrix R^T, unit weights, gradient Q^T b; the
+ *               2-dimensional null component is closed form (kernel v24, tests/algo_model.py: joint_reduction)
  *   condense    sensitivity recursion S_{k+1} = (I + dt A) S_k + dt E_k over the condensed columns
- *               [U_0..U_{H-1} | v_1..v_{nvb-1} | v_0 | affine], C += Y^T Y with Y = sqrt(Q) S on the 18 weighted rows
+ *               [y_0..y_{H-1} | v_1..v_{nvb-1} | v_0 | affine], C += Y^T Y with Y = sqrt(Q) S on the 18 weighted rows
  *               (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-200)
- *   augment     + joint weights, throttle first-difference penalty and anchor, gradient row (costsVSMPC.cpp:375-409,468-487,558-592)
+ *   augment     + unit joint weights, throttle first-difference penalty and anchor, gradient row (costsVSMPC.cpp:375-409,468-487,558-592)
  *   factor      dense Cholesky of the NZ x NZ Hessian, the gradient row carried along
  *   box QP      block principal pivoting on the Schur complement of the throttles (constraintsVSMPC.cpp:338-365),
  *               least-index fallback, as tests/algo_model.py
- *   back-subst  joints; forward simulation for the state trajectory (variableSamplingMPC.cpp:93-108)
+ *   back-subst  reduced joints; forward simulation for the state trajectory (variableSamplingMPC.cpp:93-108); U = W^-1/2 (Q y + N n)
  *
  * Linked into oracle/_build/liboracle.so together with vsmpc_oracle.c.
  */
@@ -28,6 +32,7 @@
 
 #define NX 26
 #define NJ 8
+#define NJC 6   /* reduced joint unknowns per block */
 #define NT 4
 
 typedef struct vso_config {
@@ -51,11 +56,42 @@ static const int WROW[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 20, 21, 22, 2
  * iterations.  Work arrays are allocated per call (small next to the arithmetic). */
 int vss_solve(const vso_config* c, const double* in, double* x, int* iters) {
     const int N = c->n_iter, nS = c->n_iter_small, H = c->control_horizon, nvb = H - nS + 1;
-    const int NU = NJ * H, NV = NT * nvb, NZ = NU + NV, NC = NZ + 1;   /* + the affine column */
+    const int NU = NJC * H, NV = NT * nvb, NZ = NU + NV, NC = NZ + 1;   /* + the affine column */
     const int nref = N - nS + 1;
-    double A[NX * NX], Bj[NX * NJ], Bt[NX * NT], cv[NX], dt[64], q[NX], sq[18];
-    vso_linearize(c, in, A, Bj, Bt, cv);
+    double A[NX * NX], Bj8[NX * NJ], Bj[NX * NJC], Bt[NX * NT], cv[NX], dt[64], q[NX], sq[18];
+    vso_linearize(c, in, A, Bj8, Bt, cv);
     vso_dt_schedule(c, dt);
+    /* joint reduction: columns of Ac = (Lambda W^-1/2)^T (8 x 6), b = w_reg W^-1/2 q_err rides along */
+    double Ac[8][NJC], bt[8], Vh[NJC][8], beta[NJC], isw[8];
+    for (int j = 0; j < 8; ++j) {
+        isw[j] = 1.0 / sqrt(c->w_delta_joint[j] + c->w_reg_joint_pos);
+        for (int a = 0; a < NJC; ++a) Ac[j][a] = Bj8[((a < 3 ? 3 : 6) + a) * NJ + j] * isw[j];
+        bt[j] = c->w_reg_joint_pos * in[IN_QERR + j] * isw[j];
+    }
+    for (int k = 0; k < NJC; ++k) {
+        double s2 = 0.0;
+        for (int i = k; i < 8; ++i) { s2 += Ac[i][k] * Ac[i][k]; Vh[k][i] = 0.0; }
+        for (int i = 0; i < k; ++i) Vh[k][i] = 0.0;
+        beta[k] = 0.0;
+        if (!(s2 > 1e-300)) continue;
+        const double nrm = sqrt(s2), x0 = Ac[k][k], alpha = x0 >= 0.0 ? -nrm : nrm;
+        for (int i = k; i < 8; ++i) Vh[k][i] = Ac[i][k];
+        Vh[k][k] = x0 - alpha;
+        beta[k] = 1.0 / (nrm * (nrm + fabs(x0)));
+        for (int col = k; col < NJC; ++col) {
+            double w = 0.0;
+            for (int i = k; i < 8; ++i) w += Vh[k][i] * Ac[i][col];
+            w *= beta[k];
+            for (int i = k; i < 8; ++i) Ac[i][col] -= w * Vh[k][i];
+        }
+        double w = 0.0;
+        for (int i = k; i < 8; ++i) w += Vh[k][i] * bt[i];
+        w *= beta[k];
+        for (int i = k; i < 8; ++i) bt[i] -= w * Vh[k][i];
+    }
+    memset(Bj, 0, sizeof(Bj));   /* input matrix of the reduced unknowns: R^T on the momentum rows */
+    for (int a = 0; a < NJC; ++a)
+        for (int k = 0; k <= a; ++k) Bj[((a < 3 ? 3 : 6) + a) * NJC + k] = Ac[k][a];
     memset(q, 0, sizeof(q));
     for (int i = 0; i < 3; ++i) {
         q[i] = c->w_com_pos[i]; q[3 + i] = c->w_lin_mom[i]; q[6 + i] = c->w_rpy[i]; q[9 + i] = c->w_ang_mom[i];
@@ -83,7 +119,7 @@ int vss_solve(const vso_config* c, const double* in, double* x, int* iters) {
                 const double* s = S + (size_t)t * NC;
                 for (int col = 0; col < NC; ++col) o[col] += a * s[col];
             }
-            for (int j = 0; j < NJ; ++j) o[NJ * jb + j] += Bj[r * NJ + j];
+            for (int j = 0; j < NJC; ++j) o[NJC * jb + j] += Bj[r * NJC + j];
             for (int kk = 0; kk < NV; ++kk) if (vblk[kk] == tb) o[NU + kk] += Bt[r * NT + (kk % NT)];
             o[NZ] += cv[r];
             const double* s0 = S + (size_t)r * NC;
@@ -113,8 +149,8 @@ int vss_solve(const vso_config* c, const double* in, double* x, int* iters) {
     double vprev[NT];
     for (int i = 0; i < NT; ++i) vprev[i] = v_of_throttle(in[IN_UPREV + i]);
     for (int col = 0; col < NU; ++col) {
-        M[(size_t)col * NC + col] += c->w_delta_joint[col % NJ] + c->w_reg_joint_pos;
-        M[(size_t)NZ * NC + col] += c->w_reg_joint_pos * in[IN_QERR + col % NJ];
+        M[(size_t)col * NC + col] += 1.0;                    /* |y|^2 / 2 = U^T W U / 2 in the reduced unknowns */
+        M[(size_t)NZ * NC + col] += bt[col % NJC];           /* Q^T b */
     }
     for (int a = 0; a < NV; ++a)
         for (int b = 0; b <= a; ++b) {
@@ -238,16 +274,27 @@ int vss_solve(const vso_config* c, const double* in, double* x, int* iters) {
         for (int r = 0; r < NX; ++r) {
             double f = cv[r];
             for (int t = 0; t < NX; ++t) f += A[r * NX + t] * X[t];
-            for (int j = 0; j < NJ; ++j) f += Bj[r * NJ + j] * z[NJ * jb + j];
+            for (int j = 0; j < NJC; ++j) f += Bj[r * NJC + j] * z[NJC * jb + j];
             for (int j = 0; j < NT; ++j) f += Bt[r * NT + j] * z[NU + vq + j];
             Xn[r] = X[r] + dt[k] * f;
         }
         memcpy(X, Xn, sizeof(X));
         memcpy(x + NX * (k + 1), X, sizeof(X));
     }
-    memcpy(x + NX * (N + 1), z, sizeof(double) * NU);
+    for (int i = 0; i < H; ++i) {   /* U_i = W^-1/2 H_1 .. H_6 [y_i; n], n = -N^T b */
+        double u[8];
+        for (int k = 0; k < NJC; ++k) u[k] = z[NJC * i + k];
+        u[6] = -bt[6]; u[7] = -bt[7];
+        for (int k = NJC - 1; k >= 0; --k) {
+            double w = 0.0;
+            for (int t = k; t < 8; ++t) w += Vh[k][t] * u[t];
+            w *= beta[k];
+            for (int t = k; t < 8; ++t) u[t] -= w * Vh[k][t];
+        }
+        for (int k = 0; k < 8; ++k) x[NX * (N + 1) + NJ * i + k] = u[k] * isw[k];
+    }
     for (int b = 0; b < nvb; ++b)
-        for (int j = 0; j < NT; ++j) x[NX * (N + 1) + NU + NT * b + j] = z[NU + (b == 0 ? NV - NT : NT * (b - 1)) + j];
+        for (int j = 0; j < NT; ++j) x[NX * (N + 1) + NJ * H + NT * b + j] = z[NU + (b == 0 ? NV - NT : NT * (b - 1)) + j];
     if (iters) *iters = it;
     free(z); free(M); free(Y); free(S); free(Sn); free(vblk);
     return status;

@@ -18,6 +18,13 @@ namespace vsmpc {
 constexpr int NX = VSMPC_N_STATES;   // 26
 constexpr int NJ = VSMPC_N_JOINTS;   // 8
 constexpr int NTH = VSMPC_N_THRUSTS; // 4
+// Joint reduction (kernel v24).  Every joint block enters the dynamics only through [Lambda_lin; Lambda_ang] (6 x 8, the
+// same matrix for all blocks: the model is LTI over the horizon, constraintsVSMPC.cpp:85-103), so after the orthogonal
+// change of variables  W^(1/2) U_i = Q y_i + N n  (thin QR of (Lambda W^(-1/2))^T, W = the joint weights of
+// costsVSMPC.cpp:375-381,564-591) the 2-dimensional n sees only |n|^2 / 2 + (N^T b)^T n -- closed form, the same for
+// every block -- and the condensed problem keeps NJC = 6 unknowns y_i per block with input matrix R^T, unit weights and
+// gradient Q^T b (p0_joint_reduction in vsmpc_kernels.hip; executable model: tests/algo_model.py joint_reduction).
+constexpr int NJC = 6;
 constexpr int NWROWS = 18;           // weighted state rows: 0..11 and 20..25 (costsVSMPC.cpp:78-93)
 constexpr int MAX_STAGES = 40;
 
@@ -28,16 +35,19 @@ struct Dims {
     static constexpr int NS = NS_;     // nIterSmall
     static constexpr int HC = HC_;     // controlHorizon
     static constexpr int NVB = HC - NS + 1;  // throttle blocks
-    static constexpr int NU = NJ * HC;       // joint increments
+    static constexpr int NUO = NJ * HC;      // joint increments (the reference's variables: outputs)
+    static constexpr int NUY = NJC * HC;     // reduced joint unknowns y (see NJC)
+    static constexpr int NU = ((NUY + 15) / 16) * 16;   // joint rows of the condensed problem: y, then dummy unknowns (unit
+                                             // diagonal, no coupling) up to the tile boundary the throttle rows start at
     static constexpr int NV = NTH * NVB;     // warped throttles
-    static constexpr int NZ = NU + NV;       // condensed inputs
+    static constexpr int NZ = NU + NV;       // condensed unknowns
     static constexpr int NP = ((NZ + 1 + 15) / 16) * 16;  // + gradient row, padded to tiles of 16
     static constexpr int NT = NP / 16;
     static constexpr int NTRI = NT * (NT + 1) / 2;
     static constexpr int NREF = N - NS + 1;
     static constexpr int NIN = VSMPC_IN_XREF + 12 * NREF;
     static constexpr int NXS = NX * (N + 1);
-    static constexpr int NVAR = NXS + NZ;
+    static constexpr int NVAR = NXS + NUO + NV;
     static constexpr int NCON = NXS + NTH * (N - NS + 1);
     // Y row stride (doubles), congruent 16 mod 32: the four row groups of a b64 operand read hit distinct banks
     static constexpr int YS = ((NP + 16) % 32 == 16) ? NP + 16 : NP + 32;
@@ -66,7 +76,13 @@ struct Dims {
     static constexpr int RING_A = NT;                        // tiles of an even panel column (at most NT)
     static constexpr int RING_TILES = 2 * NT - 1;            // + an odd one (at most NT - 1)
     static constexpr int NCORNER = (NT - PVT) * (NT - PVT + 1) / 2;
-    static constexpr int L_TILES = RING_TILES + NCORNER;     // LDS tiles addressed through tile_off()
+    // the corner sits behind the ring AND behind the scratch of P4..P6 that reuses the (by then dead) ring: the box-QP
+    // arrays depend on NV only, so with few joint tile rows they can be longer than the ring itself
+    static constexpr int SCRATCH_QP = 3 * NV * (NV + 1) + 2 * TS;
+    static constexpr int SCRATCH_P6 = NV * (NV + 1) + 2 * NV * (NV + 1) + NWAVES * NP + NX * (N + 1) + NX * N;
+    static constexpr int SCRATCH_TILES = ((SCRATCH_QP > SCRATCH_P6 ? SCRATCH_QP : SCRATCH_P6) + TS - 1) / TS;
+    static constexpr int CORNER_TILE0 = RING_TILES > SCRATCH_TILES ? RING_TILES : SCRATCH_TILES;
+    static constexpr int L_TILES = CORNER_TILE0 + NCORNER;   // LDS tiles addressed through tile_off()
     // Structured condensing (kernel v13, P1s in vsmpc_kernels.hip): the condensed Hessian from forward / adjoint
     // recursions of 3 HC generator columns + NV throttle columns + the affine column per half, whose forward
     // trajectories (9 N doubles) stay in the registers of the lane that owns the column.  Needs the trajectory to fit
@@ -151,7 +167,7 @@ VS_HD constexpr int throttle_block_of_stage(int k) {
     return k < D::NS ? 0 : (k < D::HC ? k - (D::NS - 1) : D::HC - D::NS);
 }
 
-// Internal condensed column order: [U_0..U_{HC-1} | v_1..v_{NVB-1} | v_0 | gradient | pad].
+// Internal condensed column order: [y_0..y_{HC-1} | dummies | v_1..v_{NVB-1} | v_0 | gradient | pad].
 // v_0 goes last so that the 20-tick throttle hold (constraintsVSMPC.cpp:351) pins the trailing block.
 template <class D>
 VS_HD constexpr int v_block_of_internal(int q) {  // q in [0, NV): internal throttle index -> reference block
@@ -161,7 +177,8 @@ VS_HD constexpr int v_block_of_internal(int q) {  // q in [0, NV): internal thro
 // first stage at which internal column c becomes non-zero in the sensitivity recursion
 template <class D>
 VS_HD constexpr int col_first_stage(int c) {
-    if (c < D::NU) return c >> 3;
+    if (c < D::NUY) return c / NJC;
+    if (c < D::NU) return 1 << 20;   // dummy unknowns: never
     if (c < D::NZ) {
         const int b = v_block_of_internal<D>(c - D::NU);
         return b == 0 ? 0 : D::NS + b - 1;

@@ -95,6 +95,15 @@ VS_DEV double readlane_f64(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// The lane id, re-derived where it is needed (two instructions) instead of carried there: a value that is live across a
+// long phase is what the register allocator spills first, and at the 2x horizon every spilled dword is 4 MB of scratch
+// traffic per 4096-instance launch.
+VS_DEV int fresh_lane() {
+    unsigned m = ~0u;
+    asm volatile("" : "+s"(m));
+    return int(__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u)));
+}
+
 // 1/sqrt(d) and 1/d: hardware seed + refinement (full double precision to ~2 ulp)
 // The v_rsq_f64 / v_rcp_f64 seeds are good to 5e-8 (profiles/r01_microbench_rsq_accuracy.txt).  One cubically
 // convergent (Halley) step y (1 + e/2 + 3 e^2/8), e = 1 - d y^2, reaches full precision in 5 instructions; two Newton
@@ -140,8 +149,12 @@ struct Smem {
     static constexpr int oFlags = oCfg + CFG_SIZE;   // 4 doubles worth of int flags
     // X_p = L_pp^-1 of the joint diagonal tiles and of the first throttle tile, produced by wavefronts that idle
     // during the panel factorisations of P3
+    // joint reduction (p0_joint_reduction): the six Householder vectors, their betas, the reduced gradient Q^T b, the null
+    // component n = -N^T b and W^(-1/2)
+    static constexpr int oQR = (oFlags + 4 + 3) & ~3;
+    static constexpr int QR_V = 0, QR_BETA = 48, QR_GY = 56, QR_NS = 62, QR_ISW = 64, QR_A = 72, QR_SIZE = 128;
     static constexpr int NXT = D::PVT + 1;
-    static constexpr int oXinv = (oFlags + 4 + 3) & ~3;
+    static constexpr int oXinv = (oQR + QR_SIZE + 3) & ~3;
     static constexpr int oR = oXinv + NXT * D::TS;
     static constexpr int YROWS = 36;                 // two nodes x 18 weighted rows = 9 exact MFMA k-steps
     static constexpr int oY = oR;
@@ -162,7 +175,7 @@ struct Smem {
     static constexpr int oX = oU + D::NWAVES * D::NP;  // P6: state trajectory
     static constexpr int oF = oX + D::NXS;           // P6: per-stage input terms, NX per stage
     static constexpr int endScratch = (oF + NX * D::N > oQP + sizeQP) ? oF + NX * D::N : oQP + sizeQP;
-    static_assert(endScratch <= oR + D::RING_TILES * D::TS, "P4..P6 scratch must not reach the corner tiles");
+    static_assert(endScratch <= oR + D::CORNER_TILE0 * D::TS, "P4..P6 scratch must not reach the corner tiles");
     // P1a: jet thrust trajectories [NJROW][N] and the affine column's momentum forcing [2][N][3], at the head of the X
     // region (the X tiles are not written before P3)
     static constexpr int NJROW = D::NV + NTH + 1;
@@ -186,7 +199,10 @@ struct Smem {
     static constexpr int AC_NSH = D::STRUCT_LONG ? D::NS : 0;           // first stored i' of a short row
     VS_HD static constexpr int ac_first(int cr) { return cr < AC_SHORT ? AC_NSH : 0; }
     VS_HD static constexpr int ac_off(int cr) {   // offset of row cr's first stored stage (4 doubles per stage)
-        return cr < AC_SHORT ? cr * (D::N - 1 - AC_NSH) * 4 : (AC_SHORT * (D::N - 1 - AC_NSH) + (cr - AC_SHORT) * (D::N - 1)) * 4;
+        // = cr < AC_SHORT ? cr (N - 1 - AC_NSH) 4 : (AC_SHORT (N - 1 - AC_NSH) + (cr - AC_SHORT) (N - 1)) 4, written without a
+        // branch: as a conditional the compiler made basic blocks of it inside p1s_entries, and at their joins moved the
+        // finished accumulator tiles through the vector registers (and a few values into scratch)
+        return 4 * (cr * (D::N - 1) - (cr < AC_SHORT ? cr : AC_SHORT) * AC_NSH);
     }
     static constexpr int sizeAc = ac_off(D::NV + 1);
     static constexpr int oSRefC = oSAc + sizeAc;
@@ -211,7 +227,7 @@ struct Smem {
 template <class D>
 VS_HD constexpr int tile_off_c(int i, int j) {
     return (j < D::PVT ? (j & 1) * D::RING_A + (i - j)
-                       : D::RING_TILES + (i - D::PVT) * (i - D::PVT + 1) / 2 + (j - D::PVT)) * D::TS;
+                       : D::CORNER_TILE0 + (i - D::PVT) * (i - D::PVT + 1) / 2 + (j - D::PVT)) * D::TS;
 }
 template <class D>
 VS_DEV int tile_off(int i, int j) { return tile_off_c<D>(i, j); }
@@ -225,7 +241,9 @@ VS_DEV int lower_at(int gr, int gc) {
 // ------------------------------------------------------------------------------------------------
 // P0: linearisation into LDS (dense, row-major) — also the body of the linearise-only kernel
 // ------------------------------------------------------------------------------------------------
-template <class D, bool ZERO = true, bool SYNC = true>
+// LAMBDA_BJ = false (the solve kernel): Bj is not filled with Lambda here -- p0_joint_reduction writes the reduced input
+// matrix R^T into it instead.
+template <class D, bool ZERO = true, bool SYNC = true, bool LAMBDA_BJ = true>
 VS_DEV void p0_linearize(int use_jet, const double* __restrict__ sIn, double* __restrict__ sA,
                          double* __restrict__ sBj, double* __restrict__ sBt, double* __restrict__ sC,
                          double* __restrict__ sVprev, int tid, int nthreads) {
@@ -299,14 +317,127 @@ VS_DEV void p0_linearize(int use_jet, const double* __restrict__ sIn, double* __
         const int e = tid - 192, r = e >> 2, j = e & 3;  // r in 0..5
         const int row = r < 3 ? 3 + r : 6 + r;         // 3..5, 9..11
         sA[row * NX + 12 + j] = sIn[VSMPC_IN_AMOM + e];
-    } else if (tid >= 216 && tid < 240) {
+    } else if (LAMBDA_BJ && tid >= 216 && tid < 240) {
         const int e = tid - 216, r = e >> 3, j = e & 7;  // Lambda_lin,B -> Bj[3..5]   (:305-306)
         sBj[(3 + r) * NJ + j] = sIn[VSMPC_IN_LLIN + e];
-    } else if (tid >= 136 && tid < 160) {
+    } else if (LAMBDA_BJ && tid >= 136 && tid < 160) {
         const int e = tid - 136, r = e >> 3, j = e & 7;  // Lambda_ang,B -> Bj[9..11]  (:94-95)
         sBj[(9 + r) * NJ + j] = sIn[VSMPC_IN_LANG + e];
     }
     if constexpr (SYNC) __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Joint reduction (see NJC in vsmpc_device.hpp), by ONE wavefront.  Householder QR of A = (Lambda W^(-1/2))^T (8 x 6):
+// lane c < 6 carries column c of A (= row c of [Lambda_lin; Lambda_ang], scaled), lane 6 the vector b = w_reg W^(-1/2)
+// q_err that rides along; step k takes its reflector from lane k (v_readlane broadcasts) and every lane behind applies
+// it to its own column.  Leaves in LDS: R^T as the joint input matrix (rows 3..5 and 9..11 of Bj, columns 0..5), the
+// reflectors v_k and beta_k (for the way back in P6), Q^T b (the gradient of the reduced unknowns), n = -N^T b and
+// W^(-1/2).  No inverse, no division by a pivot: a rank-deficient Lambda (no thrust) leaves zero columns in R^T.
+// ------------------------------------------------------------------------------------------------
+// Steps K0 .. K1 - 1 of the six; a wavefront that does not start at 0 picks the columns up from LDS where the previous
+// one left them (QR_A), so that the work can be spread over the idle stretches of different wavefronts: the first half in
+// wavefront 3 during P0 (which has only copies to do there), the second half in a generator wavefront while it waits for
+// the throttle chains -- a lone wavefront needs ~900 cycles per step (two reductions, a reciprocal square root and a
+// reciprocal in one dependent chain).
+template <class D, int K0 = 0, int K1 = NJC>
+VS_DEV void p0_joint_reduction(double* __restrict__ sm, int lane) {
+    using S = Smem<D>;
+    static_assert(VSMPC_IN_LANG == VSMPC_IN_LLIN + 24, "Lambda_lin and Lambda_ang are adjacent in the record");
+    const double* sIn = sm + S::oIn;
+    const double* sCfg = sm + S::oCfg;
+    double* sBj = sm + S::oBj;
+    double* sQR = sm + S::oQR;
+    const int c = lane < 6 ? lane : 6;   // lanes beyond 6 shadow lane 6 and store nothing
+    double a[8];
+    if constexpr (K0 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double isw = fast_rsqrt(sCfg[CFG_WJ + j]);                       // uniform
+            const double lam = sIn[VSMPC_IN_LLIN + (c < 6 ? c : 0) * 8 + j];
+            const double bq = sCfg[CFG_WREG] * sIn[VSMPC_IN_QERR + j];             // costsVSMPC.cpp:586-590
+            a[j] = (c < 6 ? lam : bq) * isw;
+            if (lane == 0) sQR[S::QR_ISW + j] = isw;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = sQR[S::QR_A + 8 * c + j];
+    }
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        // (sums as two or three partial chains: the dependent length is what a lone wavefront pays for)
+        double s0 = a[k] * a[k], s1 = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 8; i += 2) {
+            s1 = fma(a[i], a[i], s1);
+            if (i + 1 < 8) s0 = fma(a[i + 1], a[i + 1], s0);
+        }
+        const double s = s0 + s1;
+        const double sk = readlane_f64(s, k), xk = readlane_f64(a[k], k);      // the pivot column's, wave uniform
+        const bool nz = sk > 1e-300;
+        const double rs = fast_rsqrt(nz ? sk : 1.0);
+        const double nrm = nz ? sk * rs : 0.0;
+        const double alpha = xk >= 0.0 ? -nrm : nrm;
+        const double beta = nz ? rs * fast_rcp(nrm + fabs(xk)) : 0.0;          // 1 / (nrm (nrm + |x_k|))
+        double v[8];
+        v[k] = xk - alpha;
+#pragma unroll
+        for (int i = k + 1; i < 8; ++i) v[i] = readlane_f64(a[i], k);
+        double w0 = v[k] * a[k], w1 = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 8; i += 2) {
+            w1 = fma(v[i], a[i], w1);
+            if (i + 1 < 8) w0 = fma(v[i + 1], a[i + 1], w0);
+        }
+        const double w = (w0 + w1) * beta;
+        const bool behind = lane > k;
+#pragma unroll
+        for (int i = k; i < 8; ++i) a[i] = behind ? fma(-w, v[i], a[i]) : a[i];
+        a[k] = lane == k ? alpha : a[k];                                        // R[k][k]
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sQR[S::QR_V + 8 * k + i] = i >= k ? v[i] : 0.0;
+            sQR[S::QR_BETA + k] = beta;
+        }
+    }
+    if constexpr (K1 < NJC) {
+        if (lane < 7) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sQR[S::QR_A + 8 * lane + j] = a[j];
+        }
+        return;
+    }
+    if (lane < 6) {   // column `lane` of R = row `lane` of the input matrix R^T: entries k <= lane
+        const int row = lane < 3 ? 3 + lane : 6 + lane;                         // momentum rows 3..5, 9..11
+#pragma unroll
+        for (int k = 0; k < NJC; ++k) sBj[row * NJ + k] = k <= lane ? a[k] : 0.0;
+    } else if (lane == 6) {
+#pragma unroll
+        for (int k = 0; k < NJC; ++k) sQR[S::QR_GY + k] = a[k];
+        sQR[S::QR_NS + 0] = -a[6];
+        sQR[S::QR_NS + 1] = -a[7];
+    }
+}
+
+// U = W^(-1/2) H_1 ... H_6 [y; n] for one joint block (the way back from the reduced unknowns)
+template <class D>
+VS_DEV void joint_expand(const double* __restrict__ sQR, const double* __restrict__ y, double (&u)[8]) {
+    using S = Smem<D>;
+#pragma unroll
+    for (int i = 0; i < NJC; ++i) u[i] = y[i];
+    u[6] = sQR[S::QR_NS + 0];
+    u[7] = sQR[S::QR_NS + 1];
+#pragma unroll
+    for (int k = NJC - 1; k >= 0; --k) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = k; i < 8; ++i) t = fma(sQR[S::QR_V + 8 * k + i], u[i], t);   // uniform addresses: LDS broadcasts
+        t *= sQR[S::QR_BETA + k];
+#pragma unroll
+        for (int i = k; i < 8; ++i) u[i] = fma(-t, sQR[S::QR_V + 8 * k + i], u[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] *= sQR[S::QR_ISW + i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,10 +467,11 @@ __global__ __launch_bounds__(256) void linearize_kernel(DevCfg cfg, const double
 // ------------------------------------------------------------------------------------------------
 // cost terms on the condensed inputs (P2)
 // ------------------------------------------------------------------------------------------------
+// (sGy = Q^T b of the joint reduction; the reduced joint unknowns and the dummies have unit weights)
 template <class D>
-VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __restrict__ sIn,
+VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __restrict__ sGy,
                               const double* __restrict__ sVprev, int gr, int gc) {
-    if (gr < D::NU) return (gr == gc) ? sCfg[CFG_WJ + (gr & 7)] : 0.0;  // (65000+20) I  (costsVSMPC.cpp:375-381,564-571)
+    if (gr < D::NU) return (gr == gc) ? 1.0 : 0.0;   // |y|^2 / 2 = U^T W U / 2  (costsVSMPC.cpp:375-381,564-571)
     if (gr < D::NZ) {
         if (gc < D::NU) return 0.0;
         const int q1 = gr - D::NU, q2 = gc - D::NU;
@@ -351,7 +483,7 @@ VS_DEV double input_cost_term(const double* __restrict__ sCfg, const double* __r
         return (db == 1 || db == -1) ? -sCfg[CFG_WTHR] : 0.0;
     }
     if (gr == D::NZ && gc < D::NZ) {  // gradient row
-        if (gc < D::NU) return sCfg[CFG_WREG] * sIn[VSMPC_IN_QERR + (gc & 7)];      // costsVSMPC.cpp:586-590
+        if (gc < D::NU) return gc < D::NUY ? sGy[gc % NJC] : 0.0;                   // costsVSMPC.cpp:586-590, reduced
         const int q = gc - D::NU;
         return v_block_of_internal<D>(q) == 0 ? -sCfg[CFG_WINIT] * sVprev[q & 3] : 0.0;  // costsVSMPC.cpp:479-485
     }
@@ -627,7 +759,7 @@ struct WaveLists {
 
 template <class D, int TPW, int W, bool DEBUG, bool PLDS>
 VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
-                          const double* __restrict__ sIn, const double* __restrict__ sVprev, int* __restrict__ sFlags,
+                          const double* __restrict__ sGy, const double* __restrict__ sVprev, int* __restrict__ sFlags,
                           double* __restrict__ sXinv, double* __restrict__ sW, double* __restrict__ dbgL, int lane,
                           int crow, int lrow, double* sZ_) {
     constexpr TileTab<D> tab{};
@@ -647,19 +779,22 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti == tj && 16 * ti + 16 <= D::NU) {
-                const double wj = sCfg[CFG_WJ + (lane & 7)];   // (65000 + 20) on the diagonal (costsVSMPC.cpp:375-381,564-571)
+                // unit weights on the reduced joint unknowns (U^T W U / 2 = |y|^2 / 2 + |n|^2 / 2, costsVSMPC.cpp:375-381,
+                // 564-571 through the joint reduction) and on the dummy unknowns behind them
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] += ((lane >> 4) + 4 * r == (lane & 15)) ? wj : 0.0;
+                for (int r = 0; r < 4; ++r) acc[q][r] += ((lane >> 4) + 4 * r == (lane & 15)) ? 1.0 : 0.0;
             } else if constexpr (ti >= PVT && 16 * tj + 16 <= D::NU) {
-                if constexpr (ti == D::NT - 1) {   // the gradient row: w_reg * q_err (costsVSMPC.cpp:586-590)
-                    const double gq = sCfg[CFG_WREG] * sIn[VSMPC_IN_QERR + (lane & 7)];
+                if constexpr (ti == D::NT - 1) {   // the gradient row: Q^T b, b = w_reg W^(-1/2) q_err (costsVSMPC.cpp:586-590)
+                    const int gc = 16 * tj + (lane & 15);
+                    const double gv = sGy[gc % NJC];
+                    const double gq = gc < D::NUY ? gv : 0.0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[q][r] += (16 * ti + (lane >> 4) + 4 * r == D::NZ) ? gq : 0.0;
                 }
             } else if constexpr (ti == tj || ti >= PVT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[q][r] += input_cost_term<D>(sCfg, sIn, sVprev, 16 * ti + (lane >> 4) + 4 * r, 16 * tj + (lane & 15));
+                    acc[q][r] += input_cost_term<D>(sCfg, sGy, sVprev, 16 * ti + (lane >> 4) + 4 * r, 16 * tj + (lane & 15));
             }
         }
     });
@@ -1193,7 +1328,7 @@ VS_DEV void dual_active_set(const XA& xa, bool hold, int lane, double* __restric
 // number of free throttles.  Called by all wavefronts (it contains workgroup barriers); result in sZ[NU..NZ), sFlags.
 // ------------------------------------------------------------------------------------------------
 template <class D>
-VS_DEV void box_qp(int n_violated, bool hold) {
+VS_DEV void box_qp(int n_violated, bool hold, int wave) {
     using S = Smem<D>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sVprev = smem + S::oVprev;
@@ -1206,8 +1341,8 @@ VS_DEV void box_qp(int n_violated, bool hold) {
     double* Lb = smem + S::oM;
     double* sXinv = smem + S::oXinv;
     double* sQP = smem + S::oQP;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (not threadIdx.x: that would keep the work-item id register alive -- in scratch -- from the first instruction to here)
+    const int lane = fresh_lane(), tid = (wave << 6) | lane;
     constexpr bool DUALQP = S::DUALQP;
     constexpr int PV = D::PVT;
     constexpr int DUAL_MAX_ACTIVE = 16;   // (10 before the register solver for mid-size active sets: take-off batch -1.4 %)
@@ -1235,6 +1370,10 @@ VS_DEV void box_qp(int n_violated, bool hold) {
             const double* X6 = sXinv + PV * D::TS;
             const double* L76 = Lb + tile_off<D>(PV + 1, PV);
             const double* L77 = Lb + tile_off<D>(PV + 1, PV + 1);
+            // threads of the columns of X77: behind the 16 NR2 threads of T where that leaves wavefront 3 alone (it forms the
+            // right-hand side meanwhile), else the upper lanes of wavefront 3 (throttle blocks of more than 24: both run there)
+            constexpr int XT0 = 17 * NR2 <= 192 ? 16 * NR2 : 224;
+            static_assert(XT0 + NR2 <= D::BLOCK && D::NV <= 32, "threads of the X77 columns");
             if (tid < 16 * NR2) {
                 const int a2 = tid >> 4, j = tid & 15;
                 double t0 = 0.0, t1 = 0.0;
@@ -1244,8 +1383,8 @@ VS_DEV void box_qp(int n_violated, bool hold) {
                     t1 = fma(L76[a2 * 17 + k + 1], X6[(k + 1) * 17 + j], t1);
                 }
                 sT[a2 * 16 + j] = t0 + t1;
-            } else if (tid >= 128 && tid < 128 + NR2) {
-                const int c = tid - 128;                                  // column c of X77 = L77^-1
+            } else if (tid >= XT0 && tid < XT0 + NR2) {
+                const int c = tid - XT0;                                  // column c of X77 = L77^-1
                 double x[NR2];
 #pragma unroll
                 for (int i = 0; i < NR2; ++i) {
@@ -1850,15 +1989,19 @@ VS_DEV void p1s_contract(double* __restrict__ sm, int tid) {
 
 // Entries of C = sum_k Y_k^T Y_k for the accumulator tiles wavefront W owns, formed ON THE MATRIX CORES from the small LDS
 // arrays the chains leave behind, so that they arrive in the accumulator layout (lane (g, j) holds rows g + 4 r, column j)
-// with a handful of LDS reads per tile.  With L = [Lambda_lin; Lambda_ang] (6 x 8) and the k index of a product split as
-// k = 4 ks + g  ->  (kb, a6) = (g >> 1, 2 ks + (g & 1))   (kb = block within the tile, a6 = (half, a)):
-//   joint x joint        D = A B,  A[m][k] = [kb == m >> 3] L[a6][m & 7]  (the same for every tile),
-//                        B[k][n] = (H^(2 ti + kb, 2 tj + (n >> 3)) L)[a6][n & 7]                      3 k-steps
-//   throttle x joint     A[m][k] = sRb[half(a6)][row m][2 tj + kb][a],  B = the constant operand       3 k-steps
+// with a handful of LDS reads per tile.  With L = R^T (6 x 6, rows = (half, a), the input matrix of the reduced joint
+// unknowns; p0_joint_reduction) a tile row t holds the joint rows 16 t .. 16 t + 15 = unknown (16 t + j) % 6 of block
+// (16 t + j) / 6: at most FOUR blocks, the first one blk0(t) = 16 t / 6.  The k index of a product is split as
+// k = 4 ks + g  ->  (a6, kb) = (ks, g)   (a6 = (half, a), kb = block within the tile row):
+//   joint x joint        D = A B,  A[m][k] = [blk(ti, m) == blk0(ti) + kb] L[a6][unknown(ti, m)],
+//                        B[k][n] = (H^(blk0(ti) + kb, blk(tj, n)) L)[a6][unknown(tj, n)]                  6 k-steps
+//   throttle x joint     A[m][k] = sRb[half(a6)][row m][blk0(tj) + kb][a],
+//                        B[k][n] = [blk(tj, n) == blk0(tj) + kb] L[a6][unknown(tj, n)]                    6 k-steps
 //   throttle x throttle  k = (i', q): A[m][k] = sAc[row m][i'][q],  B[k][n] = [q == q_n] tau^n_{i' + 1}    N - 1 k-steps
-// Operands first, matrix instructions afterwards: with the loads of a tile right in front of its instructions every
-// tile pays LDS round trips (~9k cycles for the nine tiles of a wavefront, measured); the accumulators are not live
-// yet, so there are registers for the raw operands of all tiles at once (the loads are pinned in front of the arithmetic).
+// Rows / columns of the dummy unknowns (16 t + j >= NUY) get zero operands.  Operands first, matrix instructions
+// afterwards: with the loads of a tile right in front of its instructions every tile pays LDS round trips; the
+// accumulators are not live yet, so there are registers for the raw operands of a group of tiles at once (the loads are
+// pinned in front of the arithmetic).
 template <class D, int TPW, int W>
 VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane) {
     using S = Smem<D>;
@@ -1869,86 +2012,93 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     const double* sRb = sm + S::oSRb;
     const double* sAc = sm + S::oSAc;
     const double* sJetT = sm + S::oJetT;
+    // (opaque: the four wave-specialised copies of this function start with the same table loads, which the compiler would
+    // otherwise hoist in front of the wave dispatch and, at the 2x horizon, spill across it -- 100 registers of scratch)
+    lane = fresh_lane();
     const int j = lane & 15, g = lane >> 4;
-    const int jq = j & 7, jb1 = j >> 3;
-    const int kb = g >> 1;                       // block within the tile this lane's k values belong to
-    int hf[3], aa[3], hoff[3], roff[3];
-    double Lc[3], Lq[3][3];
+    // per lane and tile-row pattern (16 t mod 6 = 0, 4, 2 for t mod 3 = 0, 1, 2): the unknown and the block within the tile
+    // row of row / column j, and the six entries L[a6][unknown]
+    double Lq[3][NJC];
+    int bin[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-        const int a6 = 2 * ks + (g & 1);
-        hf[ks] = a6 >= 3 ? 1 : 0;
-        aa[ks] = a6 - 3 * hf[ks];
-        const int hr0 = hf[ks] ? 9 : 3;
-        const double lv = sBj[(hr0 + aa[ks]) * NJ + jq];
-        Lc[ks] = kb == jb1 ? lv : 0.0;
+    for (int pat = 0; pat < 3; ++pat) {
+        const int o = ((16 * pat) % NJC) + j;
+        bin[pat] = o / NJC;
+        const int un = o - NJC * bin[pat];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) Lq[ks][d] = sBj[(hr0 + d) * NJ + jq];
-        // everything lane dependent of an operand address, once: what is left per tile is a compile-time offset
-        //   sH : pair(2 ti + kb, 2 tj + jb1) = T(2 ti) + kb (2 ti + 1) + 2 tj + jb1,  T(n) = n (n + 1) / 2
-        hoff[ks] = (hf[ks] * D::NJPAIR + jb1) * 9 + 3 * aa[ks];
-        roff[ks] = hf[ks] * (NV + 1) * HC * 3 + kb * 3 + aa[ks];
+        for (int a6 = 0; a6 < NJC; ++a6) Lq[pat][a6] = sBj[((a6 < 3 ? 3 : 6) + a6) * NJ + un];
     }
-    const int kb9 = 9 * kb;
-    // tiles in groups of G: short horizons take all tiles of the wavefront at once (the accumulators are not live yet, so
-    // there are registers for every raw operand); long horizons (30 tiles per wavefront) go six tiles at a time
-    constexpr int G = D::STRUCT_LONG ? 6 : TPW;
+    // tiles in groups of G (the raw operands of a group are all requested before its arithmetic starts)
+    // 18 G + 12 G operand registers (doubles) beside the 18 of Lq; long horizons keep finished tiles in registers meanwhile
+    constexpr int G = D::STRUCT_LONG ? 2 : 3;
     constexpr int NGRP = (TPW + G - 1) / G;
     static_for<0, NGRP>([&](auto gcst) __attribute__((always_inline)) {
     constexpr int q0 = decltype(gcst)::value * G;
     constexpr int q1 = q0 + G < TPW ? q0 + G : TPW;
-    double raw[G][3][3];
+    double raw[G][NJC][3];
     static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
-            if constexpr (ti < PVT && ti != tj) {
-                constexpr int base = ((2 * ti) * (2 * ti + 1) / 2 + 2 * tj) * 9;
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const double* Hp = sH + base + hoff[ks] + kb9 * (2 * ti + 1);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) raw[q - q0][ks][d] = Hp[d];
-                }
-            } else if constexpr (ti < PVT) {
-                // diagonal tile: its upper block (row block 2 t, column block 2 t + 1) is the transposed lower one
-                const int br = 2 * ti + kb, bc = 2 * ti + jb1;
-                const bool sw = br < bc;
+            if constexpr (ti < PVT) {
+                // H^(br, bc), br = blk0(ti) + g (this lane's k block), bc = the block of column j of tile column tj; stored
+                // for br >= bc, transposed otherwise (diagonal tiles only).  Blocks beyond the horizon belong to dummy rows /
+                // columns whose other operand is zero: clamped into the array.
+                constexpr int b0r = (16 * ti) / NJC, b0c = (16 * tj) / NJC;
+                const int brr = b0r + g, bcc = b0c + bin[tj % 3];
+                const int br = brr < HC ? brr : HC - 1, bc = bcc < HC ? bcc : HC - 1;
+                const bool sw = ti == tj && br < bc;
                 const int hi = sw ? bc : br, lo = sw ? br : bc;
+                const int st = sw ? 3 : 1, sa = sw ? 1 : 3;
+                const double* Hp = sH + (hi * (hi + 1) / 2 + lo) * 9;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const double* Hp = sH + (hf[ks] * D::NJPAIR + hi * (hi + 1) / 2 + lo) * 9 + (sw ? aa[ks] : 3 * aa[ks]);
-                    const int st = sw ? 3 : 1;
+                for (int ks = 0; ks < NJC; ++ks) {
+                    const double* Hk = Hp + (ks / 3) * D::NJPAIR * 9 + sa * (ks % 3);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) raw[q - q0][ks][d] = Hp[d * st];
+                    for (int d = 0; d < 3; ++d) raw[q - q0][ks][d] = Hk[d * st];
                 }
             } else if constexpr (tj < PVT) {
+                constexpr int b0c = (16 * tj) / NJC;
                 const int cr = 16 * (ti - PVT) + j;
                 const int crc = cr <= NV ? cr : NV;
+                const int bcc = b0c + g, bc = bcc < HC ? bcc : HC - 1;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) raw[q - q0][ks][0] = sRb[(crc * HC + 2 * tj) * 3 + roff[ks]];
+                for (int ks = 0; ks < NJC; ++ks)
+                    raw[q - q0][ks][0] = sRb[(((ks / 3) * (NV + 1) + crc) * HC + bc) * 3 + (ks % 3)];
             }
         }
     });
     __builtin_amdgcn_sched_barrier(0);
-    double op[G][3];
+    double opa[G][NJC], opb[G][NJC];
     static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
-        op[q - q0][0] = op[q - q0][1] = op[q - q0][2] = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < NJC; ++ks) { opa[q - q0][ks] = 0.0; opb[q - q0][ks] = 0.0; }
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti < PVT) {
+                const bool okm = 16 * ti + j < D::NUY && bin[ti % 3] == g;   // A: row j of tile row ti sits in k block g
+                const bool okn = 16 * tj + j < D::NUY;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks)
-                    op[q - q0][ks] = fma(raw[q - q0][ks][2], Lq[ks][2], fma(raw[q - q0][ks][1], Lq[ks][1], raw[q - q0][ks][0] * Lq[ks][0]));
+                for (int ks = 0; ks < NJC; ++ks) {
+                    const int h3 = 3 * (ks / 3);
+                    const double hl = fma(raw[q - q0][ks][2], Lq[tj % 3][h3 + 2],
+                                          fma(raw[q - q0][ks][1], Lq[tj % 3][h3 + 1], raw[q - q0][ks][0] * Lq[tj % 3][h3]));
+                    opa[q - q0][ks] = okm ? Lq[ti % 3][ks] : 0.0;
+                    opb[q - q0][ks] = okn ? hl : 0.0;
+                }
             } else if constexpr (tj < PVT) {
-                const bool ok = 16 * (ti - PVT) + j <= NV;
+                const bool okr = 16 * (ti - PVT) + j <= NV;
+                const bool okn = 16 * tj + j < D::NUY && bin[tj % 3] == g;
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) op[q - q0][ks] = ok ? raw[q - q0][ks][0] : 0.0;
+                for (int ks = 0; ks < NJC; ++ks) {
+                    opa[q - q0][ks] = okr ? raw[q - q0][ks][0] : 0.0;
+                    opb[q - q0][ks] = okn ? Lq[tj % 3][ks] : 0.0;
+                }
             }
         }
     });
@@ -1957,15 +2107,17 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         constexpr TileTab<D> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
-        d4 c = d4{0.0, 0.0, 0.0, 0.0};
+        d4 c = d4{0.0, 0.0, 0.0, 0.0}, c2 = d4{0.0, 0.0, 0.0, 0.0};
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
-            if constexpr (ti < PVT) {
+            if constexpr (tj < PVT) {
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Lc[ks], op[q - q0][ks], c, 0, 0, 0);
-            } else if constexpr (tj < PVT) {
+                for (int ks = 0; ks < NJC; ks += 2) {   // two accumulators (a dependent FP64 matrix instruction issues every ~95 cycles)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[q - q0][ks], opb[q - q0][ks], c, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(opa[q - q0][ks + 1], opb[q - q0][ks + 1], c2, 0, 0, 0);
+                }
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) c = __builtin_amdgcn_mfma_f64_16x16x4f64(op[q - q0][ks], Lc[ks], c, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) c[r] += c2[r];
             }
         }
         acc[q] = c;
@@ -1984,31 +2136,46 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
             if constexpr (ti >= PVT && tj >= PVT) {
                 constexpr int K0 = tile_first_stage<D>(tj);   // first k-step (stage i' = i - 1)
                 constexpr int NK = N - 1 - K0;
+                // (lane-derived values are formed afresh here: carried across the joint tiles above they were spilled)
+                const int ln = fresh_lane(), j = ln & 15, g = ln >> 4;
                 const int cr = 16 * (ti - PVT) + j, cc = 16 * (tj - PVT) + j;
                 const bool okr = cr <= NV, okc = cc < NV && g == (cc & 3);
                 const int crc = okr ? cr : NV;
                 const int rfirst = S::ac_first(crc);
                 const double* Ap = sAc + S::ac_off(crc) - 4 * rfirst + g;
                 const double* Tp = sJetT + (cc < NV ? cc : 0) * N + 1;
-                double av[NK], bv[NK];
-#pragma unroll
-                for (int ks = 0; ks < NK; ++ks) {
-                    const int ip = K0 + ks;
-                    if (D::STRUCT_LONG && ip < S::AC_NSH) av[ks] = ip >= rfirst ? Ap[4 * ip] : 0.0;
-                    else av[ks] = Ap[4 * ip];
-                    bv[ks] = Tp[ip];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < NK; ++ks) { av[ks] = okr ? av[ks] : 0.0; bv[ks] = okc ? bv[ks] : 0.0; }
+                // operand pairs in chunks of CH k-steps (all of them at short horizons): at the 2x horizon a tile has up to 33
+                // k-steps, and 66 operand registers requested at once were spilled to scratch as they arrived
+                constexpr int CH = D::STRUCT_LONG ? 8 : NK;
                 // two accumulators: a dependent v_mfma_f64_16x16x4_f64 issues every ~95 cycles, independent ones every 64
                 // (tools/microbench/lat_probe.hip)
                 d4 c = d4{0.0, 0.0, 0.0, 0.0}, c2 = d4{0.0, 0.0, 0.0, 0.0};
+                static_for<0, (NK + CH - 1) / CH>([&](auto ccst) __attribute__((always_inline)) {
+                    constexpr int k0 = decltype(ccst)::value * CH;
+                    constexpr int kn = k0 + CH < NK ? CH : NK - k0;
+                    double av[kn], bv[kn];
 #pragma unroll
-                for (int ks = 0; ks < NK; ++ks) {
-                    if (ks & 1) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c2, 0, 0, 0);
-                    else c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
-                }
+                    for (int ks = 0; ks < kn; ++ks) {
+                        const int ip = K0 + k0 + ks;
+                        // (a short row does not store the stages before rfirst: the load then hits the row in front of it --
+                        // always inside the workgroup's LDS -- and is discarded below; a conditional load would be a branch)
+                        av[ks] = Ap[4 * ip];
+                        bv[ks] = Tp[ip];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < kn; ++ks) {
+                        const int ip = K0 + k0 + ks;
+                        const bool stored = !(D::STRUCT_LONG && ip < S::AC_NSH) || ip >= rfirst;
+                        av[ks] = (okr && stored) ? av[ks] : 0.0;
+                        bv[ks] = okc ? bv[ks] : 0.0;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < kn; ++ks) {
+                        if ((k0 + ks) & 1) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c2, 0, 0, 0);
+                        else c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], c, 0, 0, 0);
+                    }
+                });
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c[r] += c2[r];
                 acc[q] = c;
@@ -2078,6 +2245,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         }                                                                  \
     } while (0)
     using S = Smem<D>;
+    constexpr bool FUSED_DISPATCH = FORM == 1 && !STAMPS;   // entries + P2 + P3 behind one wave dispatch (see P1)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sIn = smem + S::oIn;
     double* sA = smem + S::oA;
@@ -2126,7 +2294,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(0);
     // ---------------------------------------------------------------- P0
     {   // 16 B per lane: the record stride (NIN doubles) and the LDS base are multiples of 16 B
-        static_assert(D::NIN % 2 == 0 && D::NVAR % 2 == 0 && D::NXS % 2 == 0 && D::NU % 2 == 0, "double2 I/O");
+        static_assert(D::NIN % 2 == 0 && D::NVAR % 2 == 0 && D::NXS % 2 == 0 && D::NUO % 2 == 0, "double2 I/O");
         // the record's HBM round trip (~1 us) is overlapped with the LDS initialisation: loads first, dependent stores last
         static_assert(D::NIN / 2 <= D::BLOCK, "one 16-byte load per thread covers the record");
         const double2* in2 = reinterpret_cast<const double2*>(in + size_t(inst) * D::NIN);
@@ -2145,7 +2313,15 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         if (tid < D::NIN / 2) sIn2[tid] = rec;
     }
     __syncthreads();
-    p0_linearize<D, false, false>(cfg.use_jet, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);  // barrier: after P1a below
+    p0_linearize<D, false, false, false>(cfg.use_jet, sIn, sA, sBj, sBt, sC, sVprev, tid, D::BLOCK);  // barrier: after P1a below
+    // joint reduction: 6 unknowns per joint block instead of 8 (NJC).  The SYRK form needs the reduced input matrix at the top
+    // of its recursion: all six steps here, in wavefront 3, which has only copies to do in P0 (5.6 k cycles, of which ~2.8 k
+    // lengthen P0).  The structured form needs it for the tile entries only: three steps here (hidden), the other three in a
+    // generator wavefront after its chain, in the ~3 k cycles it would otherwise wait for the throttle wavefronts (below).
+    if (wave == 3) {
+        if constexpr (FORM == 1) p0_joint_reduction<D, 0, 3>(smem, lane);
+        else p0_joint_reduction<D>(smem, lane);
+    }
 
     // P1a: jet sub-system.  The model is a cascade (jets -> momenta -> CoM / RPY -> integrators) and the jets are
     // decoupled from each other, so of the condensed columns only the throttle columns (one jet each) and the affine
@@ -2213,8 +2389,13 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // tiles straight into the accumulator registers.
         static_assert(D::STRUCT_P1, "structured condensing is instantiated for horizons with Dims::STRUCT_P1");
         VS_TIC();
-        if (wave < 2) p1s_chain<D, 0>(cfg, wave, lane, smem);
-        else p1s_chain<D, 1>(cfg, wave - 2, lane, smem);
+        if (wave < 2) {
+            p1s_chain<D, 0>(cfg, wave, lane, smem);
+            if (wave == 0) p0_joint_reduction<D, 3, NJC>(smem, lane);   // (second half; writes Bj and sQR, which nobody touches
+                                                                        // before the barrier below)
+        } else {
+            p1s_chain<D, 1>(cfg, wave - 2, lane, smem);
+        }
         VS_TOC(0);
         __syncthreads();
         VS_TOC(1);
@@ -2223,6 +2404,26 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             __syncthreads();
         }
         VS_TOC(3);
+        if constexpr (FUSED_DISPATCH) {
+            // the shipped structured form: ONE wave dispatch for the entries, P2 and P3 -- the accumulator tiles are born and
+            // factored inside one branch, no join in between (at a join the allocator moved the tiles of a wavefront through
+            // the vector registers, and at the 2x horizon pushed other values into scratch to make room)
+            auto tail = [&](auto wcst) __attribute__((always_inline)) {
+                constexpr int W = decltype(wcst)::value;
+                p1s_entries<D, TPW, W>(acc, smem, lane);
+                __syncthreads();   // the LDS arrays of P1s lie under the ring P3 is about to fill
+                if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
+                const int ln = fresh_lane();
+                cholesky_wave<D, TPW, W, false, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, nullptr, ln,
+                                                      (ln >> 4) * 17 + (ln & 15), (ln & 15) * 17 + (ln >> 4), sZ);
+            };
+            switch (wave) {
+                case 0: tail(std::integral_constant<int, 0>{}); break;
+                case 1: tail(std::integral_constant<int, 1>{}); break;
+                case 2: tail(std::integral_constant<int, 2>{}); break;
+                default: tail(std::integral_constant<int, 3>{}); break;
+            }
+        } else {
         switch (wave) {
             case 0: p1s_entries<D, TPW, 0>(acc, smem, lane); break;
             case 1: p1s_entries<D, TPW, 1>(acc, smem, lane); break;
@@ -2231,6 +2432,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         }
         VS_TOC(2);
         __syncthreads();   // the LDS arrays of P1s lie under the ring P3 is about to fill
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
@@ -2281,8 +2483,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             col[cc] = c;
             kind[cc] = 3;
             blk[cc] = 0;
-            if (c < D::NU) { kind[cc] = 0; blk[cc] = c >> 3; comp = c & 7; }
-            else if (c < D::NZ) { kind[cc] = 1; blk[cc] = v_block_of_internal<D>(c - D::NU); comp = (c - D::NU) & 3; }
+            if (c < D::NUY) { kind[cc] = 0; blk[cc] = c / NJC; comp = c - NJC * blk[cc]; }   // (dummy unknowns: kind 3)
+            else if (c >= D::NU && c < D::NZ) { kind[cc] = 1; blk[cc] = v_block_of_internal<D>(c - D::NU); comp = (c - D::NU) & 3; }
             else if (c == D::NZ) { kind[cc] = 2; }
             // unconditional loads (every address is valid for every column), selected afterwards: conditional loads
             // become branches and the LDS latencies add up instead of overlapping
@@ -2459,7 +2661,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 if (ti_q == tj_q || ti_q >= PVT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        tmp[r] += input_cost_term<D>(sCfg, sIn, sVprev, 16 * ti_q + (lane >> 4) + 4 * r,
+                        tmp[r] += input_cost_term<D>(sCfg, smem + S::oQR + S::QR_GY, sVprev, 16 * ti_q + (lane >> 4) + 4 * r,
                                                      16 * tj_q + (lane & 15));
                 }
 #pragma unroll
@@ -2472,11 +2674,12 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     VS_STAMP(3);
     VS_REFRESH_IDS();
+    if constexpr (!FUSED_DISPATCH)
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
-        case 1: cholesky_wave<D, TPW, 1, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
-        case 2: cholesky_wave<D, TPW, 2, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
-        default: cholesky_wave<D, TPW, 3, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, sIn, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 0: cholesky_wave<D, TPW, 0, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 1: cholesky_wave<D, TPW, 1, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 2: cholesky_wave<D, TPW, 2, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        default: cholesky_wave<D, TPW, 3, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
     }
     static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
     if (STAMPS && dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
@@ -2666,7 +2869,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_REFRESH_IDS();
 
     if (need_qp) {
-        box_qp<D>(sFlags[3], hold);
+        box_qp<D>(sFlags[3], hold, wave);
         __syncthreads();
         VS_STAMP(6);
         VS_REFRESH_IDS();
@@ -2695,7 +2898,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(7);
     VS_REFRESH_IDS();
     // ---------------------------------------------------------------- P6 forward simulation + outputs
-    // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c
+    // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c  (Bj U = R^T y in the reduced unknowns)
     for (int e = tid; e < NX * D::N; e += D::BLOCK) {
         const int k = e / NX, r = e - k * NX;
         const int jb = joint_block_of_stage<D>(k);
@@ -2703,7 +2906,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
         double f = sC[r];
 #pragma unroll
-        for (int c = 0; c < NJ; ++c) f += sBj[r * NJ + c] * sZ[NJ * jb + c];
+        for (int c = 0; c < NJC; ++c) f += sBj[r * NJ + c] * sZ[NJC * jb + c];
 #pragma unroll
         for (int c = 0; c < NTH; ++c) f += sBt[r * NTH + c] * sV[vq + c];
         sF[e] = f;
@@ -2745,6 +2948,15 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             cx = sIn[VSMPC_IN_X0 + cxr]; cee = sIn[VSMPC_IN_X0 + cer];
             sX[cxr] = cx;
             sX[cer] = cee;
+        }
+        // wavefront 3 (no link of the cascade) takes the reduced joint unknowns back to joint increments meanwhile:
+        // U_i = W^(-1/2) (Q y_i + N n), one block per lane, into the (dead) partial-sum array of P5
+        static_assert(D::NUO <= D::NWAVES * D::NP, "joint increments fit the partial-sum array");
+        if (wave == 3 && lane < D::HC) {
+            double u8[8];
+            joint_expand<D>(smem + S::oQR, sZ + NJC * lane, u8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sU[NJ * lane + i] = u8[i];
         }
         static_for<0, NCH + 2>([&](auto scst) __attribute__((always_inline)) {
             constexpr int st = decltype(scst)::value;
@@ -2847,16 +3059,16 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     if (xout != nullptr) {
         double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
         for (int i = tid; i < D::NXS / 2; i += D::BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
-        for (int i = tid; i < D::NU / 2; i += D::BLOCK) xo[D::NXS / 2 + i] = make_double2(sZ[2 * i], sZ[2 * i + 1]);
+        for (int i = tid; i < D::NUO / 2; i += D::BLOCK) xo[D::NXS / 2 + i] = make_double2(sU[2 * i], sU[2 * i + 1]);
         if (tid < D::NV / 2) {  // reference order v_0..v_{NVB-1}
             const int e = 2 * tid, b = e >> 2, c = e & 3;
             const int q = b == 0 ? D::NV - 4 + c : 4 * (b - 1) + c;
-            xo[(D::NXS + D::NU) / 2 + tid] = make_double2(sV[q], sV[q + 1]);
+            xo[(D::NXS + D::NUO) / 2 + tid] = make_double2(sV[q], sV[q + 1]);
         }
     }
     if (fmout != nullptr && tid < VSMPC_FM_SIZE) {
         double v;
-        if (tid < 8) v = sZ[tid];                                        // delta q           (variableSamplingMPC.cpp:99)
+        if (tid < 8) v = sU[tid];                                        // delta q           (variableSamplingMPC.cpp:99)
         else if (tid < 12) v = sV[D::NV - 4 + (tid - 8)];                // v0                (:100)
         else if (tid < 16) v = Jet::throttle_of_v(sV[D::NV - 4 + (tid - 12)]);  // throttle % (:146-149)
         else if (tid < 20) v = sX[NX + 12 + (tid - 16)];                 // thrust, node 1    (:101)

@@ -25,27 +25,121 @@ import numpy as np
 W_ROWS = list(range(0, 12)) + list(range(20, 26))  # the 18 weighted state rows (costsVSMPC.cpp:78-93)
 
 
-def column_maps(cfg):
-    """Internal input ordering [U | v_1..v_{nvb-1} | v_0] -> (kind, block, component)."""
+NJC = 6   # condensed joint variables per block after the joint reduction (kernel v24): rank of [Lambda_lin; Lambda_ang]
+
+
+def column_maps(cfg, njc=8):
+    """Internal input ordering [U | pad | v_1..v_{nvb-1} | v_0] -> (kind, block, component).  njc = 8: the joint increments
+    themselves; njc = 6: the reduced joint variables y (joint_reduction), padded with dummy columns ("pad") to a multiple
+    of 16 so that the throttle rows start on a tile boundary."""
     H, nvb = cfg.control_horizon, cfg.n_vblocks
-    cols = [("U", j, q) for j in range(H) for q in range(8)]
+    cols = [("U", j, q) for j in range(H) for q in range(njc)]
+    cols += [("pad", 0, 0)] * (joint_rows(cfg, njc) - njc * H)
     cols += [("v", b, i) for b in range(1, nvb) for i in range(4)]
     cols += [("v", 0, i) for i in range(4)]
     return cols
 
 
-def condense_syrk(cfg, oracle, inp):
+def joint_rows(cfg, njc=8):
+    n = njc * cfg.control_horizon
+    return n if njc == 8 else ((n + 15) // 16) * 16
+
+
+def joint_reduction(Lam6, wj, b):
+    """Every joint block enters the dynamics only through Lam6 = [Lambda_lin; Lambda_ang] (6 x 8, the same for all blocks:
+    the model is LTI over the horizon, constraintsVSMPC.cpp:85-103), and its cost is 1/2 U^T W U + w_reg q_err^T U with
+    W = diag(weightDeltaJoint + weightRegularizationJointPos) (costsVSMPC.cpp:375-381,564-591).  With ut = W^(1/2) U and
+    the Householder QR  (Lam6 W^(-1/2))^T = [Q N] [R; 0]  the change of variables ut = Q y + N n gives
+        Lam6 U = R^T y,    1/2 U^T W U = 1/2 (|y|^2 + |n|^2),    b^T ut = (Q^T b)^T y + (N^T b)^T n,  b = w_reg W^(-1/2) q_err
+    so n = -N^T b in closed form (the same for every block) and the condensed problem keeps 6 unknowns y per block with
+    input matrix R^T, unit weights and gradient Q^T b.  No inverse is formed: a rank-deficient Lam6 (zero thrust) just
+    leaves zero columns in R^T.  Returns (Beff = R^T 6 x 6, gy (6), nstar (2), V (6 reflectors, 8 each), beta (6))."""
+    isw = 1.0 / np.sqrt(wj)
+    Acol = (Lam6 * isw[None, :]).T.copy()          # 8 x 6
+    bt = b * isw
+    V = np.zeros((6, 8))
+    beta = np.zeros(6)
+    for k in range(6):
+        x = Acol[k:, k]
+        s = float(x @ x)
+        if s > 1e-300:
+            nrm = np.sqrt(s)
+            alpha = -np.copysign(nrm, x[0])
+            v = x.copy()
+            v[0] -= alpha
+            beta[k] = 1.0 / (nrm * (nrm + abs(x[0])))
+            V[k, k:] = v
+            Acol[k:, k:] -= beta[k] * np.outer(v, v @ Acol[k:, k:])
+            bt[k:] -= beta[k] * v * (v @ bt[k:])
+    R = np.triu(Acol[:6, :6])
+    return R.T.copy(), bt[:6].copy(), -bt[6:].copy(), V, beta
+
+
+def joint_expand(y, nstar, V, beta, wj):
+    """U = W^(-1/2) H_1 ... H_6 [y; n]"""
+    u = np.concatenate([y, nstar])
+    for k in range(5, -1, -1):
+        u -= beta[k] * V[k] * (V[k] @ u)
+    return u / np.sqrt(wj)
+
+
+def reduced_condensed(cfg, oracle, inp):
+    """What the device's condensed problem must be, derived from the oracle's REFERENCE-ORDERED dense QP (null-space
+    elimination of the states, no condensing recursion) and the joint reduction: returns (M, g, L) in the kernel's order
+    [y_0..y_{H-1} | dummies | v_1..v_{nvb-1} | v_0] -- M = T^T Hr T, g = T^T (Hr u0 + gr) with U = T [y; v] + u0."""
+    N, H, nvb = cfg.n_iter, cfg.control_horizon, cfg.n_vblocks
+    nxs, NUo, NV = 26 * (N + 1), 8 * H, 4 * nvb
+    Hd, gd, Ac, lo, hi = oracle.assemble_dense(cfg, inp)
+    sol = np.linalg.solve(Ac[:nxs, :nxs], np.column_stack([lo[:nxs], Ac[:nxs, nxs:]]))
+    Z = np.vstack([-sol[:, 1:], np.eye(NUo + NV)])
+    xp = np.concatenate([sol[:, 0], np.zeros(NUo + NV)])
+    Hr, gr = Z.T @ Hd @ Z, Z.T @ (Hd @ xp + gd)
+    perm = list(range(NUo)) + list(range(NUo + 4, NUo + NV)) + list(range(NUo, NUo + 4))   # [U | v1.. | v0]
+    Hr, gr = Hr[np.ix_(perm, perm)], gr[perm]
+    _, red = reduced_model(cfg, oracle, inp)
+    E = np.column_stack([joint_expand(np.eye(NJC)[i], np.zeros(2), red["V"], red["beta"], red["wj"]) for i in range(NJC)])  # W^-1/2 Q
+    u_n = joint_expand(np.zeros(NJC), red["nstar"], red["V"], red["beta"], red["wj"])                                      # W^-1/2 N n
+    NU = joint_rows(cfg, NJC)
+    NZ = NU + NV
+    T = np.zeros((NUo + NV, NZ))
+    u0 = np.zeros(NUo + NV)
+    for i in range(H):
+        T[8 * i:8 * i + 8, NJC * i:NJC * i + NJC] = E
+        u0[8 * i:8 * i + 8] = u_n
+    T[NUo:, NU:] = np.eye(NV)
+    M = T.T @ Hr @ T
+    g = T.T @ (Hr @ u0 + gr)
+    for d in range(NJC * H, NU):
+        M[d, d] = 1.0
+    L = np.linalg.cholesky(0.5 * (M + M.T))
+    return M, g, L
+
+
+def reduced_model(cfg, oracle, inp):
+    """(A, Bj_eff 26 x 6, Bt, c) and the reduction's by-products for the record `inp`"""
+    A, Bj, Bt, c = oracle.linearize(cfg, inp)
+    wj = np.asarray(cfg.w_delta_joint, float) + cfg.w_reg_joint_pos
+    Lam6 = np.vstack([Bj[3:6, :], Bj[9:12, :]])
+    Beff, gy, nstar, V, beta = joint_reduction(Lam6, wj, cfg.w_reg_joint_pos * inp[oracle.IN_QERR:oracle.IN_QERR + 8])
+    Bje = np.zeros((26, NJC))
+    Bje[3:6] = Beff[0:3]
+    Bje[9:12] = Beff[3:6]
+    return (A, Bje, Bt, c), dict(gy=gy, nstar=nstar, V=V, beta=beta, wj=wj)
+
+
+def condense_syrk(cfg, oracle, inp, lin=None, njc=8):
     """P1 as the sensitivity recursion + SYRK (kernels up to v12): the padded C = sum_k Y_k^T Y_k, whose row / column
-    NZ (the affine column) holds the condensed gradient of the tracking cost."""
+    NZ (the affine column) holds the condensed gradient of the tracking cost.  `lin` = (A, Bj, Bt, c) with njc joint
+    columns per block replaces the record's own linearisation (the reduced model)."""
     N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
-    NU, NV = 8 * H, 4 * cfg.n_vblocks
+    NU, NV = joint_rows(cfg, njc), 4 * cfg.n_vblocks
     NZ = NU + NV
     NP = ((NZ + 1 + 15) // 16) * 16
-    A, Bj, Bt, c = oracle.linearize(cfg, inp)
+    A, Bj, Bt, c = oracle.linearize(cfg, inp) if lin is None else lin
     dts = oracle.dt_schedule(cfg)
     qd = oracle.state_weight(cfg)
     sq = np.sqrt(qd[W_ROWS])
-    cols = column_maps(cfg)
+    cols = column_maps(cfg, njc)
     xref_win = inp[oracle.IN_XREF:oracle.IN_XREF + 12 * cfg.n_ref_cols].reshape(cfg.n_ref_cols, 12)
     S = np.zeros((26, NP))
     S[:, NZ] = inp[0:26]  # affine column starts at x0
@@ -73,35 +167,47 @@ def condense_syrk(cfg, oracle, inp):
     return C
 
 
-def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None, condense=None):
+def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None, condense=None, reduce=False, out=None):
     """`oracle` is the oracle module (for linearize/dt_schedule helpers that restate the reference);
-    everything downstream of (A, Bj, Bt, c) is the kernel's own algorithm."""
+    everything downstream of (A, Bj, Bt, c) is the kernel's own algorithm.  reduce=True: with the joint reduction in front
+    (6 unknowns per joint block, kernel v24); `out` (a dict) receives the condensed matrices M and L."""
     N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
     nvb = cfg.n_vblocks
-    NU, NV = 8 * H, 4 * nvb
+    njc = NJC if reduce else 8
+    NU, NV = joint_rows(cfg, njc), 4 * nvb
     NZ = NU + NV
     NP = ((NZ + 1 + 15) // 16) * 16
-    A, Bj, Bt, c = oracle.linearize(cfg, inp)
+    red = None
+    if reduce:
+        (A, Bj, Bt, c), red = reduced_model(cfg, oracle, inp)
+    else:
+        A, Bj, Bt, c = oracle.linearize(cfg, inp)
     dts = oracle.dt_schedule(cfg)
     qd = oracle.state_weight(cfg)
     sq = np.sqrt(qd[W_ROWS])
-    cols = column_maps(cfg)
+    cols = column_maps(cfg, njc)
     vmin, vmax = oracle.throttle_bounds(cfg)
     vprev = np.array([oracle.v_of_throttle(inp[oracle.IN_UPREV + i]) for i in range(4)])
     hold = inp[oracle.IN_HOLD] != 0.0
     xref_win = inp[oracle.IN_XREF:oracle.IN_XREF + 12 * cfg.n_ref_cols].reshape(cfg.n_ref_cols, 12)
 
     # ---- P1 condense
-    C = condense_syrk(cfg, oracle, inp) if condense is None else condense(cfg, oracle, inp)
+    lin = (A, Bj, Bt, c) if reduce else None
+    C = condense_syrk(cfg, oracle, inp, lin, njc) if condense is None else condense(cfg, oracle, inp, lin, njc)
 
     # ---- P2 augment with R and the input-cost gradient
     M = C.copy()
     gz = np.zeros(NZ)
     wj = np.asarray(cfg.w_delta_joint) + cfg.w_reg_joint_pos
     for ci, (kind, blk, comp) in enumerate(cols):
-        if kind == "U":
+        if kind == "U" and not reduce:
             M[ci, ci] += wj[comp]
             gz[ci] = cfg.w_reg_joint_pos * inp[oracle.IN_QERR + comp]
+        elif kind == "U":
+            M[ci, ci] += 1.0                 # |y|^2 / 2: unit weights in the reduced variables
+            gz[ci] = red["gy"][comp]
+        elif kind == "pad":
+            M[ci, ci] += 1.0                 # dummy unknowns: decoupled, solution 0
     vidx = {(blk, comp): ci for ci, (kind, blk, comp) in enumerate(cols) if kind == "v"}
     for i in range(4):
         for b in range(nvb - 1):
@@ -126,6 +232,8 @@ def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None, conde
         Lf[j, j] = d * inv
         for k2 in range(j + 1, NZ + 1):
             Lf[k2:, k2] -= Lf[k2:, j] * Lf[k2, j]
+    if out is not None:
+        out["M"], out["L"] = M, Lf
     Lm = Lf[:NZ, :NZ]
     ghat = Lf[NZ, :NZ]          # = L^-1 g
     y = -ghat
@@ -214,8 +322,10 @@ def solve_model(cfg, oracle, inp, max_bpp_iter=60, dual=False, trace=None, conde
     for k in range(N):
         jb = oracle.joint_block_of_stage(cfg, k)
         tb = oracle.throttle_block_of_stage(cfg, k)
-        X = X + dts[k] * (A @ X + Bj @ U[8 * jb:8 * jb + 8] + Bt @ vref[4 * tb:4 * tb + 4] + c)
+        X = X + dts[k] * (A @ X + Bj @ U[njc * jb:njc * jb + njc] + Bt @ vref[4 * tb:4 * tb + 4] + c)
         x[26 * (k + 1):26 * (k + 2)] = X
-    x[cfg.off_joints:cfg.off_joints + NU] = U
+    if reduce:   # back to joint increments: U_i = W^(-1/2) (Q y_i + N n)
+        U = np.concatenate([joint_expand(U[njc * i:njc * i + njc], red["nstar"], red["V"], red["beta"], red["wj"]) for i in range(H)])
+    x[cfg.off_joints:cfg.off_joints + 8 * H] = U
     x[cfg.off_throttle:cfg.off_throttle + NV] = vref
     return x, status, iters

@@ -28,7 +28,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from algo_model import column_maps
+from algo_model import column_maps, joint_rows
 
 HALVES = (
     # x rows, h rows, e rows
@@ -43,7 +43,7 @@ def jet_trajectories(cfg, oracle, A, Bt, c, inp):
     N = cfg.n_iter
     dts = oracle.dt_schedule(cfg)
     cols = column_maps(cfg)
-    NU = 8 * cfg.control_horizon
+    NU = 8 * cfg.control_horizon    # (throttle columns are looked up in the un-reduced column map)
     NV = 4 * cfg.n_vblocks
     tau = np.zeros((NV, N))
     Tbar = np.zeros((4, N))
@@ -81,17 +81,18 @@ def half_operators(A, half):
     return K
 
 
-def condense_structured(cfg, oracle, inp):
+def condense_structured(cfg, oracle, inp, lin=None, njc=8):
     """Returns the padded condensed matrix (NP x NP): C in [0:NZ, 0:NZ], the condensed gradient of the tracking cost in
-    row / column NZ, the constant term at [NZ, NZ] -- i.e. what sum_k Y_k^T Y_k gives in algo_model.solve_model."""
+    row / column NZ, the constant term at [NZ, NZ] -- i.e. what sum_k Y_k^T Y_k gives in algo_model.solve_model.
+    `lin` / `njc`: the reduced model of algo_model.reduced_model (6 joint columns per block, input matrix R^T)."""
     N, nS, H = cfg.n_iter, cfg.n_iter_small, cfg.control_horizon
-    NU, NV = 8 * H, 4 * cfg.n_vblocks
+    NU, NV = joint_rows(cfg, njc), 4 * cfg.n_vblocks
     NZ = NU + NV
     NP = ((NZ + 1 + 15) // 16) * 16
-    A, Bj, Bt, c = oracle.linearize(cfg, inp)
+    A, Bj, Bt, c = oracle.linearize(cfg, inp) if lin is None else lin
     dts = oracle.dt_schedule(cfg)
     qd = oracle.state_weight(cfg)
-    cols = column_maps(cfg)
+    cols = column_maps(cfg, njc)
     xref_win = inp[oracle.IN_XREF:oracle.IN_XREF + 12 * cfg.n_ref_cols].reshape(cfg.n_ref_cols, 12)
     tau, Tbar = jet_trajectories(cfg, oracle, A, Bt, c, inp)
 
@@ -100,7 +101,7 @@ def condense_structured(cfg, oracle, inp):
         xs, hs, es = HALVES[half]
         K = half_operators(A, half)
         Q = np.diag(np.concatenate([qd[xs], qd[hs], qd[es]]))
-        Lam = Bj[hs, :]            # 3 x 8
+        Lam = Bj[hs, :]            # 3 x 8 (3 x 6 in the reduced model)
         Am = A[hs, 12:16]          # 3 x 4
         ch, ce = c[hs], c[es]
         Abar = [np.eye(9) + dts[m] * K for m in range(N)]
@@ -140,7 +141,7 @@ def condense_structured(cfg, oracle, inp):
                 if kind == "U":
                     if oracle.joint_block_of_stage(cfg, i) == blk:
                         prof[ci, i] = Lam[:, comp]
-                else:
+                elif kind == "v":
                     prof[ci, i] = Am[:, comp] * tau[ci - NU, i]
         W = np.einsum("ijab,cjb->cia", Hm, prof)          # W_c(i) = sum_i' H(i, i') pi_c(i')
         C[:NZ, :NZ] += np.einsum("ria,cia->rc", prof, W)

@@ -56,25 +56,22 @@ def test_dense_assembly_matches_oracle(mpc, ref, synth, layout):
 
 
 def test_condensed_hessian_and_factor(mpc, ref, synth, layout):
-    """Block-by-block check of the device condensing (P1/P2) and Cholesky (P3)."""
+    """Block-by-block check of the device condensing (P1/P2) and Cholesky (P3) against the oracle's dense, reference-
+    ordered QP taken through the joint reduction (tests/algo_model.py: reduced_condensed): 6 unknowns per joint block,
+    8 dummy unknowns up to the tile boundary, condensed dimension 104 (+ the gradient row) instead of 120."""
+    import algo_model
     cfg, rcfg = layout.paper_config(), ref.paper_config()
     rec = synth.make_batch(cfg, 2, workload="takeoff")[1]
+    assert mpc.n_p == 112
     M, Lf = mpc.debug_condensed(rec)
-    H, g, Ac, lo, hi = ref.assemble_dense(rcfg, rec)
-    nxs = 468
-    sol = np.linalg.solve(Ac[:nxs, :nxs], np.column_stack([lo[:nxs], Ac[:nxs, nxs:]]))
-    Z = np.vstack([-sol[:, 1:], np.eye(120)])
-    xp = np.concatenate([sol[:, 0], np.zeros(120)])
-    Hr = Z.T @ H @ Z
-    gr = Z.T @ (H @ xp + g)
-    perm = list(range(96)) + list(range(100, 120)) + list(range(96, 100))   # kernel order [U | v1..v5 | v0]
-    Hr, gr = Hr[np.ix_(perm, perm)], gr[perm]
-    Mh = np.tril(M[:120, :120])
+    Me, ge, Le = algo_model.reduced_condensed(rcfg, ref, rec)
+    nz = Me.shape[0]
+    assert nz == 104
+    Mh = np.tril(M[:nz, :nz])
     Mh = Mh + np.tril(Mh, -1).T
-    assert relerr(Mh, Hr) < 1e-12 and relerr(M[120, :120], gr) < 1e-12
-    Lr = np.linalg.cholesky(0.5 * (Hr + Hr.T))
-    assert relerr(np.tril(Lf[:120, :120]), Lr) < 1e-11
-    assert relerr(Lf[120, :120], np.linalg.solve(Lr, gr)) < 1e-11
+    assert relerr(Mh, Me) < 1e-12 and relerr(M[nz, :nz], ge) < 1e-12
+    assert relerr(np.tril(Lf[:nz, :nz]), Le) < 1e-11
+    assert relerr(Lf[nz, :nz], np.linalg.solve(Le, ge)) < 1e-11
 
 
 def test_box_qp_both_formulations_match_oracle(mpc, ref, synth, layout):
@@ -282,9 +279,10 @@ def test_structured_and_syrk_condensing_agree(mpc, solver_mod, synth, layout):
     np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_array_equal(a[3], b[3])
     assert relerr(a[0], b[0]) < 1e-11 and relerr(a[1], b[1]) < 1e-11
-    # (entry [120, 120], the constant term of the cost, is not formed by the structured form: nothing reads it)
-    assert relerr(np.tril(Ma[:121, :120]), np.tril(Mb[:121, :120])) < 1e-13
-    assert relerr(np.tril(La[:121, :120]), np.tril(Lb[:121, :120])) < 1e-12
+    # (entry [NZ, NZ], the constant term of the cost, is not formed by the structured form: nothing reads it)
+    nz = 104   # 6 x 12 reduced joint unknowns + 8 dummies + 24 throttles
+    assert relerr(np.tril(Ma[:nz + 1, :nz]), np.tril(Mb[:nz + 1, :nz])) < 1e-13
+    assert relerr(np.tril(La[:nz + 1, :nz]), np.tril(Lb[:nz + 1, :nz])) < 1e-12
     with pytest.raises(ValueError):
         mpc.set_kernel_form(7)
 
@@ -481,7 +479,7 @@ def test_horizon2x_structured_and_syrk_condensing_agree(mpc2x, solver_mod, synth
         Mb, Lb = mpc2x.debug_condensed(recs[5])[:2]
     finally:
         mpc2x.set_kernel_form(prev)
-    nz = 236
+    nz = 188   # 6 x 24 reduced joint unknowns + 44 throttles
     assert relerr(np.tril(Ma[:nz + 1, :nz]), np.tril(Mb[:nz + 1, :nz])) < 1e-13
     assert relerr(np.tril(La[:nz + 1, :nz]), np.tril(Lb[:nz + 1, :nz])) < 1e-11
     np.testing.assert_array_equal(a[2], b[2])
@@ -490,11 +488,11 @@ def test_horizon2x_structured_and_syrk_condensing_agree(mpc2x, solver_mod, synth
 
 
 def test_horizon2x_golden_and_oracle(mpc2x, ref, synth, layout, golden_h2x):
-    """BASELINE.json configs[4]: 2x horizon at halved fast-rate dt (1146 variables, 994 rows, condensed dimension 236).
+    """BASELINE.json configs[4]: 2x horizon at halved fast-rate dt (1146 variables, 994 rows, condensed dimension 188).
     The factor stays in registers + the LDS panel ring for this variant too (one workgroup per CU); many throttle bounds are
     active."""
     cfg, rcfg = layout.horizon2x_config(), ref.horizon2x_config()
-    assert mpc2x.n_var == 1146 and mpc2x.n_con == 994 and mpc2x.n_in == 414 and mpc2x.n_p == 240
+    assert mpc2x.n_var == 1146 and mpc2x.n_con == 994 and mpc2x.n_in == 414 and mpc2x.n_p == 192
     x, fm, st, it = mpc2x.solve(golden_h2x["inputs"])
     assert (st == layout.STATUS_SOLVED).all()
     for b in range(len(x)):
@@ -522,19 +520,14 @@ def test_horizon2x_blocks_and_batch(mpc2x, ref, synth, layout):
     np.testing.assert_allclose(dt, ref.dt_schedule(rcfg), rtol=0, atol=1e-17)
     Ar, Bjr, Btr, cr = ref.linearize(rcfg, recs[1])
     assert relerr(A[1], Ar) < 1e-13 and relerr(c[1], cr) < 1e-13
+    import algo_model
     M, Lf = mpc2x.debug_condensed(recs[1])
-    H, g, Ac, lo, hi = ref.assemble_dense(rcfg, recs[1])
-    nxs = 26 * 35
-    sol = np.linalg.solve(Ac[:nxs, :nxs], np.column_stack([lo[:nxs], Ac[:nxs, nxs:]]))
-    Z = np.vstack([-sol[:, 1:], np.eye(236)])
-    xp = np.concatenate([sol[:, 0], np.zeros(236)])
-    Hr, gr = Z.T @ H @ Z, Z.T @ (H @ xp + g)
-    perm = list(range(192)) + list(range(196, 236)) + list(range(192, 196))
-    Hr, gr = Hr[np.ix_(perm, perm)], gr[perm]
-    Mh = np.tril(M[:236, :236]); Mh = Mh + np.tril(Mh, -1).T
-    assert relerr(Mh, Hr) < 1e-11 and relerr(M[236, :236], gr) < 1e-11
-    Lr = np.linalg.cholesky(0.5 * (Hr + Hr.T))
-    assert relerr(np.tril(Lf[:236, :236]), Lr) < 1e-10
+    Me, ge, Le = algo_model.reduced_condensed(rcfg, ref, recs[1])
+    nz = Me.shape[0]
+    assert nz == 188
+    Mh = np.tril(M[:nz, :nz]); Mh = Mh + np.tril(Mh, -1).T
+    assert relerr(Mh, Me) < 1e-11 and relerr(M[nz, :nz], ge) < 1e-11
+    assert relerr(np.tril(Lf[:nz, :nz]), Le) < 1e-10
     # a full 256-instance launch: determinism + feasibility properties
     big = synth.make_batch(cfg, 64, workload="takeoff")
     big = np.tile(big, (4, 1))
@@ -556,7 +549,7 @@ def test_general_horizon_21_9_15(solver_mod, ref, synth, layout):
     assert cfg.n_var == 26 * 22 + 8 * 15 + 4 * 7 and cfg.n_con == 26 * 22 + 4 * 13
     m = solver_mod.BatchedVSMPC(cfg, device=0, max_batch=64)
     try:
-        assert "21,9,15" in m.kernel_name.replace(" ", "") and m.n_p == 160
+        assert "21,9,15" in m.kernel_name.replace(" ", "") and m.n_p == 128
         recs = np.concatenate([synth.make_batch(cfg, 12, workload=w, first_index=5) for w in ("hover", "takeoff", "montecarlo")])
         A, Bj, Bt, c, dt = m.linearize(recs[:2])
         np.testing.assert_allclose(dt, ref.dt_schedule(rcfg), rtol=0, atol=1e-17)

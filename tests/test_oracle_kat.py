@@ -159,6 +159,40 @@ def test_algorithm_model_matches_oracle(ref, golden_paper, golden_h2x, which):
         assert iters == int(gold["iters"][i])
 
 
+@pytest.mark.parametrize("which", ["paper", "h2x"])
+def test_joint_reduction_reaches_the_oracles_optimum(ref, golden_paper, golden_h2x, which):
+    """Kernel v24's joint reduction (6 unknowns per joint block: Householder QR of (Lambda W^-1/2)^T, closed-form null
+    component; algo_model.joint_reduction) in front of either condensing form: the oracle's optimum and the oracle's
+    active-set iteration counts, also with a rank-deficient Lambda (no thrust: Lambda = 0; linear = angular rows: rank 3),
+    and the condensed matrices equal the oracle's dense reference-ordered QP taken through the change of variables."""
+    import algo_model
+    import condense_model
+    gold, cfg = (golden_paper, ref.paper_config()) if which == "paper" else (golden_h2x, ref.horizon2x_config())
+    for i, rec in enumerate(gold["inputs"][:6]):
+        for cond in (None, condense_model.condense_structured):
+            out = {}
+            xm, status, iters = algo_model.solve_model(cfg, ref, rec, reduce=True, condense=cond, out=out)
+            assert status == 1 and iters == int(gold["iters"][i])
+            assert np.abs(xm - gold["x"][i]).max() / max(1.0, np.abs(gold["x"][i]).max()) < 1e-10
+        if i == 0:
+            Me, ge, Le = algo_model.reduced_condensed(cfg, ref, rec)
+            nz = Me.shape[0]
+            assert nz == (104 if which == "paper" else 188)
+            scale = np.abs(Me).max()
+            assert np.abs(out["M"][:nz, :nz] - Me).max() < 1e-12 * scale and np.abs(out["M"][nz, :nz] - ge).max() < 1e-11 * np.abs(ge).max()
+            assert np.abs(np.tril(out["L"][:nz, :nz]) - Le).max() < 1e-11 * np.abs(Le).max()
+    rec = gold["inputs"][0].copy()
+    for variant in ("zero", "rank3"):
+        r = rec.copy()
+        if variant == "zero":
+            r[ref.IN_LLIN:ref.IN_LLIN + 48] = 0.0
+        else:
+            r[ref.IN_LANG:ref.IN_LANG + 24] = r[ref.IN_LLIN:ref.IN_LLIN + 24]
+        xm, status, iters = algo_model.solve_model(cfg, ref, r, reduce=True)
+        xo, _, ito, _ = ref.solve_instance(cfg, r)
+        assert status == 1 and iters == ito and np.abs(xm - xo).max() / max(1.0, np.abs(xo).max()) < 1e-10
+
+
 def test_dual_and_primal_box_qp_iterates_agree(ref, synth, layout):
     """The dual form of the box QP (P = S_NN^-1 = X^T X, mu = P_AA^-1 (v_u,A - b_A)) that the kernel runs for few
     active bounds walks through the same active sets, throttles and multipliers as the primal form on the Schur
