@@ -8,8 +8,9 @@
 One *step* = one pass of the hot path (linearise -> condense -> factor -> box QP -> simulate) over one
 batch of synthetic instances that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]
 (batch=256 hover initial states, paper horizon/rates).  With N > 1 ranks the line carries BASELINE.json configs[3] --
-the Monte-Carlo batch sharded over the GPUs, 4096 instances with 4x wider scatter per rank, per-rank seeds, no
-data-path collective (weak scaling) -- and the 256-per-GPU figure moves into `extra_configs`.
+the Monte-Carlo batch sharded over the GPUs, 4096 instances with 4x wider scatter per rank, every instance seeded by its
+GLOBAL index (1234 + index: the batch does not depend on the number of ranks), no data-path collective (weak scaling) --
+and the 256-per-GPU figure moves into `extra_configs`.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -83,18 +84,70 @@ def kernel_form(mpc, batch, dev):
 
 def counters_of(config: str, workload: str, batch: int):
     """Counter-derived figures of this configuration from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json,
-    profiles/mfma_counters.json; tools/prof_r03.sh).  They describe the kernel version named in `counters_from`, measured
-    on the builder's lease -- NOT this run."""
+    profiles/mfma_counters.json; tools/prof_r04.sh).  They describe the kernel version named in `counters_from`, measured
+    on the builder's lease -- NOT this run.
+      executed_flops_per_solve  what the wavefronts actually executed: FP64 matrix-core FLOPs (SQ_INSTS_VALU_MFMA_MOPS_F64
+                                x 512) + FP64 vector FLOPs (64 lanes x (ADD + MUL + 2 FMA + TRANS) instructions, an upper
+                                bound: masked-off lanes are counted).  `frac` is NOT built from it: SURVEY 8(d) fixes the
+                                numerator to the method-independent F_alg.
+      bound                     what the counters say the kernel waits for (summarize_mfma.py: matrix pipe busy share,
+                                wave time parked / issuing)."""
     key = f"{config}:{workload}:{batch}"
-    out = {"traffic": None, "mfma_busy_frac": None, "counters_from": None}
-    for fname, field, dst in (("hbm_traffic.json", "bytes_per_launch", "traffic"), ("mfma_counters.json", "mfma_busy_frac", "mfma_busy_frac")):
+    out = {"traffic": None, "mfma_busy_frac": None, "counters_from": None, "executed_flops_per_solve": None, "bound": None,
+           "wave_time_shares": None}
+    for fname, fields in (("hbm_traffic.json", (("bytes_per_launch", "traffic"),)),
+                          ("mfma_counters.json", (("mfma_busy_frac", "mfma_busy_frac"), ("executed_flops_per_instance", "executed_flops_per_solve"),
+                                                  ("bound", "bound"), ("wave_time_shares", "wave_time_shares")))):
         path = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(path):
             rec = json.load(open(path)).get(key)
             if rec:
-                out[dst] = rec.get(field)
+                for field, dst in fields:
+                    out[dst] = rec.get(field)
                 out["counters_from"] = rec.get("tag", out["counters_from"])
     return out
+
+
+def surface_latency(ticks: int = 2000):
+    """p50 / p99 of update(qpInput) + solveMPC() through the reference-side binding -- VariableSamplingMPCT<QPInput,
+    TrajectoryManager> exactly as INTEGRATION.md section 2 shows it (tests/cpp/integration_snippet.cpp), over the
+    signature stand-ins of tests/cpp/refstub, batch 1, one vsmpc_tick submission per tick -- measured by a compiled C++
+    driver in its own process (std::chrono around the two calls).  What a 200 Hz drop-in user of the class sees."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import fake_provider as fp
+        consts = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_constants.json")))
+        traj = dict(np.load(os.path.join(ROOT, "tests", "golden", "reference_trajectories.npz")))
+        tmp = tempfile.mkdtemp(prefix="vsmpc_surface_")
+        exe = os.path.join(tmp, "reference_surface_driver")
+        cpp = os.path.join(ROOT, "tests", "cpp")
+        pkg_dir = os.path.join(ROOT, PKG)
+        cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(cpp, "refstub"), "-I", cpp,
+               os.path.join(cpp, "reference_surface_driver.cpp"), "-o", exe, "-L", pkg_dir, "-lvsmpc", f"-Wl,-rpath,{pkg_dir}",
+               "-Wl,-rpath,/opt/rocm/lib"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            return {"note": "driver did not build: " + res.stderr[-300:]}
+        sc = fp.Scenario(n_ticks=45, seed=17)
+        scen = os.path.join(tmp, "scenario.bin")
+        open(scen, "wb").write(sc.serialise(consts, traj, list(range(3, 11))).tobytes())
+        out = {}
+        for form, extra in (("fused", []), ("two_call", ["two-call"])):
+            res = subprocess.run([exe, scen, "-", "latency", str(ticks)] + extra, capture_output=True, text=True, timeout=120)
+            if res.returncode != 0:
+                return {"note": f"driver failed ({res.returncode}): {res.stdout[-200:]}"}
+            out[form] = json.loads(res.stdout.strip().splitlines()[-1])
+        return {"p50": out["fused"]["p50_us"], "p99": out["fused"]["p99_us"], "mean": out["fused"]["mean_us"],
+                "entry": "VariableSamplingMPCT::update + solveMPC -> vsmpc_tick (kinematics -> record -> solve in one "
+                         "submission through the mapped staging buffer, one synchronisation)",
+                "two_call_form": {"p50": out["two_call"]["p50_us"], "p99": out["two_call"]["p99_us"],
+                                  "entry": "update -> vsmpc_kinematics_batch (synchronous), solveMPC -> vsmpc_solve_batch"},
+                "what": f"batch=1, {ticks} ticks of a 45-state provider scenario, {out['fused']['solved']} solved; host wall-clock "
+                        "of the two calls in a C++ process; reference: 2.18 ms per tick (poster, hardware unstated)"}
+    except Exception as exc:  # pragma: no cover - needs g++ and the test fixtures
+        return {"note": f"unavailable ({type(exc).__name__}: {exc})"}
 
 
 def parity_sample(cfg_name: str, inputs: np.ndarray, x: np.ndarray, k: int = 8) -> float:
@@ -155,9 +208,8 @@ def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, wor
         dist.barrier()
     elapsed = time.perf_counter() - t0
     red_dev = dev if red_dev is None else red_dev
-    own = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)   # this rank's own wall-clock for the K steps
     red = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
-    lo = own.clone()
+    lo = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)   # this rank's own wall-clock for the K steps
     cnt = torch.tensor([int((d_st == 1).sum().item()), int(d_it.sum().item()), 1], dtype=torch.int64, device=red_dev)
     if distributed:
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
@@ -180,7 +232,10 @@ def measure_extra(spec, pkg, synth, solver, sharding, dev, local_rank, rank, wor
                "rccl_ranks": int(cnt[2].item()) if distributed else 1,
                "per_rank_solves_per_s": {"min": B * spec["steps"] / elapsed, "max": B * spec["steps"] / float(lo[0].item())},
                "parity_max_rel_err_vs_oracle": parity_sample(spec["config"], inputs, x_host, k=6)}
-        rec.update(counters_of(spec["config"], spec["workload"], B))
+        ctr = counters_of(spec["config"], spec["workload"], B)
+        rec.update(ctr)
+        if ctr["executed_flops_per_solve"]:
+            rec["executed_frac"] = ctr["executed_flops_per_solve"] * B / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
     mpc.close()
     return rec
 
@@ -321,8 +376,17 @@ def main():
                        "parallelism": f"batch split over {world} GPU(s), no data-path collective"},
             "rccl_ranks": rccl_ranks, "collective_backend": ("rccl" if not rehearsal else backend + " (rehearsal, not a measurement)") if distributed else None,
             "per_rank_solves_per_s": {"min": count * args.steps / elapsed, "max": count * args.steps / fastest},
-            "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": ctr["traffic"],
+            # `frac` prices the METHOD-INDEPENDENT algorithmic FLOPs against the FP64 peak: an equivalent-throughput
+            # figure.  `bound` says what the counters show the kernel is limited by -- dependent-instruction issue in lone
+            # wavefronts, not the matrix pipe -- and `executed_*` what the wavefronts actually executed.
+            "roofline": {"bound": ctr["bound"] or "issue", "peak_of": "fp64 mfma/fma", "achieved": achieved_tflops,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / FP64_PEAK_TFLOPS, "frac_is": "algorithmic FLOPs (F_alg) / time / peak",
+                         "executed_flops_per_solve": ctr["executed_flops_per_solve"],
+                         "executed_frac": (ctr["executed_flops_per_solve"] * count / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+                                           if ctr["executed_flops_per_solve"] else None),
+                         "wave_time_shares": ctr["wave_time_shares"],
+                         "traffic": ctr["traffic"],
                          "mfma_busy_frac": ctr["mfma_busy_frac"], "counters_from": ctr["counters_from"],
                          "kernel": mpc.kernel_name, "kernel_form": kernel_form(mpc, B, dev),
                          "kernel_us_per_launch": kernel_ms * 1e3,
@@ -334,6 +398,7 @@ def main():
         out["parity_max_rel_err_vs_oracle"] = parity_sample(args.config, inputs, x_host)
         if not args.no_latency:
             one = solver.BatchedVSMPC(cfg, device=local_rank, max_batch=1)
+            one_host = solver.BatchedVSMPC(cfg, device=local_rank, max_batch=1)
             lat = []
             for i in range(1020):
                 torch.cuda.synchronize(dev)
@@ -344,8 +409,22 @@ def main():
             lat = np.array(lat[20:])
             out["latency_single_solve_us"] = {"p50": float(np.percentile(lat, 50) * 1e6),
                                               "p99": float(np.percentile(lat, 99) * 1e6),
+                                              "entry": "vsmpc_solve_batch_device (record and outputs resident in HBM)",
                                               "what": "batch=1, 1000 repeats, host wall-clock incl. launch + sync"}
             one.close()
+            rec1 = np.ascontiguousarray(inputs[:1])
+            lat = []
+            for i in range(1020):
+                a = time.perf_counter()
+                mpc_host_x = one_host.solve(rec1)
+                lat.append(time.perf_counter() - a)
+            lat = np.array(lat[20:])
+            out["latency_host_entry_us"] = {"p50": float(np.percentile(lat, 50) * 1e6), "p99": float(np.percentile(lat, 99) * 1e6),
+                                            "entry": "vsmpc_solve_batch (host record in, host results out, mapped staging buffer)",
+                                            "what": "batch=1, 1000 repeats through the ctypes wrapper (solver.BatchedVSMPC.solve)"}
+            one_host.close()
+            if world == 1:
+                out["latency_reference_surface_us"] = surface_latency()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, inputs)
             out["cpu_structured"] = cpu_structured(args.config, inputs)

@@ -326,6 +326,15 @@ int vsmpc_rollout_run(vsmpc_rollout* r, int ticks, double* log, void* stream);
  * track, angular-momentum reference = I_G W RPYDot at the attitude of the push), [n_traj][3] each, at the position
  * trajectory's rate; NULL = all zero (the shipped files).  Call before vsmpc_rollout_reset. */
 int vsmpc_rollout_set_attitude_tracks(vsmpc_rollout* r, const double* traj_rpy, const double* traj_rpy_dot);
+/* Kinematic-tree plant: with a tree set, the plant's joint vectoring IS the kinematics the MPC linearises -- every tick the
+ * batched kinematics provider (vsmpc_provider_batch's device code) is evaluated on the plant's own joint state, in the body
+ * frame, and A_mom,body(q), the locked inertia I_B(q) and Lambda_lin,B / Lambda_ang,B (through vsmpc_kinematics_batch's
+ * device code, from the tree's Jacobians) replace the plant parameters AMOM0 / DJ / INERTIA_B: what the harness does when it
+ * refreshes the Robot from the simulator state every tick (src/mujoco_lib/ironcub_mujoco_simulator.py:318-346 ->
+ * utils/src/Robot.cpp:198-335).  PP_MASS must be the tree's total mass; the controlled joints are the tree's eight
+ * (tree->robot_joint[j] = 3 + j for the default selector).  NULL switches back to the parametric plant.  Call before
+ * vsmpc_rollout_reset; a tick is then six launches instead of two (still replayed from a captured graph). */
+int vsmpc_rollout_set_tree(vsmpc_rollout* r, const vsmpc_tree* tree);
 int vsmpc_rollout_get_state(vsmpc_rollout* r, double* state);
 int vsmpc_rollout_get_records(vsmpc_rollout* r, double* records);
 

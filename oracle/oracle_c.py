@@ -151,16 +151,43 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def available_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota where there is one (a GPU
+    box hands one job a share of the host: 16 CPUs per GPU on this pool, whatever the affinity mask says)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def host_threads(lib, avail):
+    """worker threads of the CPU legs: every core this process may use (north_star: "the node's own host cores, core
+    count stated"); VSMPC_CPU_THREADS caps it (it used to default to 16)"""
+    cap = int(os.environ.get("VSMPC_CPU_THREADS", "0"))
+    n = min(lib.vso_max_threads(), avail)
+    return max(1, min(n, cap) if cap > 0 else n)
+
+
 def time_structured(cfg_name, inputs, budget_s=8.0):
     """bench.py's `cpu_structured` leg: the condensed exact solve (the kernel's algorithm) in C on the host cores."""
     import vsmpc_ref as ref
     rcfg = ref.paper_config() if cfg_name == "paper" else ref.horizon2x_config()
     lib, c = load(), make_cfg(rcfg)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(lib.vso_max_threads(), avail, int(os.environ.get("VSMPC_CPU_THREADS", "16"))))
+    avail = available_cpus()
+    cores = host_threads(lib, avail)
 
     def run(arr, threads, budget):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
@@ -172,7 +199,7 @@ def time_structured(cfg_name, inputs, budget_s=8.0):
     want = int(cores * (budget_s * 3 / 4) / (ms1 * 1e-3)) + cores
     reps = max(1, -(-want // len(inputs)))
     el, n, stats = run(np.tile(inputs, (reps, 1)), cores, budget_s * 3 / 4)
-    return {"value": n / el, "unit": "solves/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+    return {"value": n / el, "unit": "solves/s", "cores": cores, "cores_available": avail, "host_logical_cpus": os.cpu_count(), "kind": "port", "cpu": cpu_model(),
             "single_thread_ms_per_solve": ms1,
             "sample": f"{n} solves on {cores} threads in {el:.1f} s + {n1} single-thread solves ({ms1:.3f} ms each); scalar C "
                       f"of the kernel's own algorithm (condense -> Cholesky -> box QP on the throttles, mean "
@@ -182,15 +209,12 @@ def time_structured(cfg_name, inputs, budget_s=8.0):
 
 def time_baseline(cfg_name, inputs, budget_s=15.0):
     """bench.py's cpu_baseline leg: a single-thread latency sample, then a throughput sample on the host cores this
-    process may use (capped at 16 = the CPU share of a one-GPU box), about `budget_s` seconds of wall time in all."""
+    process may use (all of them; `cores_available` = what the affinity mask allows), about `budget_s` seconds in all."""
     import vsmpc_ref as ref
     rcfg = ref.paper_config() if cfg_name == "paper" else ref.horizon2x_config()
     lib = load()
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(lib.vso_max_threads(), avail, int(os.environ.get("VSMPC_CPU_THREADS", "16"))))
+    avail = available_cpus()
+    cores = host_threads(lib, avail)
     one = time_batch(rcfg, inputs[:min(len(inputs), 256)], threads=1, budget_s=budget_s / 8)
     ms1 = 1e3 * one["elapsed_s"] / max(1, one["done"])
     onew = time_batch(rcfg, inputs[:min(len(inputs), 256)], threads=1, budget_s=budget_s / 8, warm=True)
@@ -198,7 +222,8 @@ def time_baseline(cfg_name, inputs, budget_s=15.0):
     want = int(cores * (budget_s * 4 / 5) / (ms1 * 1e-3)) + cores          # enough work for the remaining budget
     reps = max(1, -(-want // len(inputs)))
     allc = time_batch(rcfg, np.tile(inputs, (reps, 1)), threads=cores, budget_s=budget_s * 4 / 5)
-    return {"value": allc["done"] / allc["elapsed_s"], "unit": "solves/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+    return {"value": allc["done"] / allc["elapsed_s"], "unit": "solves/s", "cores": cores, "cores_available": avail, "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "cpu": cpu_model(),
             "single_thread_ms_per_solve": ms1, "single_thread_ms_per_solve_warm_started": ms1w,
             "warm_start_mean_iters": onew["mean_iters"],
             "sample": f"{allc['done']} solves (the benchmark batch repeated) on {cores} threads in {allc['elapsed_s']:.1f} s "

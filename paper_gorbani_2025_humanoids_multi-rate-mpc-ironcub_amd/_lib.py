@@ -19,7 +19,7 @@ EXPORTS = (
     "vsmpc_rollout_create", "vsmpc_rollout_destroy", "vsmpc_rollout_reset", "vsmpc_rollout_run",
     "vsmpc_rollout_get_state", "vsmpc_rollout_get_records", "vsmpc_alloc_host", "vsmpc_free_host",
     "vsmpc_set_kernel_form", "vsmpc_set_kinematics_options", "vsmpc_provider_batch", "vsmpc_rollout_set_attitude_tracks",
-    "vsmpc_tick",
+    "vsmpc_tick", "vsmpc_rollout_set_tree",
     # include/vsmpc_jet.h
     "vsmpc_jet_create", "vsmpc_jet_destroy", "vsmpc_jet_nn_step", "vsmpc_jet_nn_sequence", "vsmpc_jet_ekf_update",
     "vsmpc_jet_plant_run", "vsmpc_jet_plant_run_device", "vsmpc_rollout_set_jet_plant",
@@ -96,6 +96,8 @@ def load():
     lib.vsmpc_provider_batch.restype = c_int
     lib.vsmpc_rollout_set_attitude_tracks.argtypes = [vp, dp, dp]
     lib.vsmpc_rollout_set_attitude_tracks.restype = c_int
+    lib.vsmpc_rollout_set_tree.argtypes = [vp, vp]
+    lib.vsmpc_rollout_set_tree.restype = c_int
     lib.vsmpc_tick.argtypes = [vp, dp, dp, c_int, dp, dp, vp, vp, vp]
     lib.vsmpc_tick.restype = c_int
     lib.vsmpc_rollout_set_jet_plant.argtypes = [vp, vp, dp, dp]

@@ -82,6 +82,11 @@ struct vsmpc_rollout {
     hipGraphExec_t gexec;     // GRAPH_TICKS ticks (3 launches each) captured once, replayed per chunk
     int graph_state;          // 0 not built yet, 1 ready, -1 capture unavailable (direct launches only)
     int graph_form;           // h->form the graph was captured with (vsmpc_set_kernel_form on the handle rebuilds it)
+    // kinematic-tree plant (vsmpc_rollout_set_tree)
+    int use_tree;
+    vsmpc_tree tree;
+    double* d_rs;             // provider states [batch][VSMPC_RS_SIZE]
+    double* d_ro;             // Robot-level outputs of the provider [batch][VSMPC_RO_SIZE]
 };
 
 namespace {
@@ -114,6 +119,28 @@ Stage stage_view(const vsmpc_handle* h, double* base) {
     v.it = v.st + ZC_MAX;
     v.kin = v.fm + size_t(ZC_MAX) * (VSMPC_FM_SIZE + 1);
     return v;
+}
+
+// Tree plant of a rollout: provider on the body-frame states (joints + this tick's move when `fm` is given), then the
+// kinematics terms of those records (I_B for the plant's integration; the Lambda terms are formed again after the advance,
+// with the thrusts it measured).  The handle's kinematics buffers are the rollout's scratch, like its solve buffers.
+hipError_t enqueue_tree(vsmpc_rollout* r, const double* fm, const int* status, hipStream_t s) {
+    vsmpc_handle* h = r->h;
+    hipError_t e = launch_tree_state(r->rd, r->batch, r->d_state, fm, status, r->d_rs, s);
+    if (e == hipSuccess) e = launch_provider(r->tree, r->d_rs, r->batch, h->d_kin, r->d_ro, nullptr, h->n_in, s);
+    if (e == hipSuccess) {
+        KinOpts o = h->kin;
+        o.constant_lambda = 0;
+        e = launch_kinematics(h->d_kin, r->batch, h->d_kout, o, s);
+    }
+    return e;
+}
+// Lambda_lin,B | Lambda_ang,B of the tree at the thrusts the advance kernel left in the kinematics records -> r->d_rec
+hipError_t enqueue_tree_lambda(vsmpc_rollout* r, hipStream_t s) {
+    KinOpts o = r->h->kin;
+    o.constant_lambda = 0;
+    o.skip_inertia = 1;   // the record's I_G = R I_B R^T is the advance kernel's (the tree is evaluated in the body frame)
+    return launch_kinematics_patch(r->h->d_kin, r->batch, r->d_rec, r->h->n_in, o, s);
 }
 
 // dt schedule: constraintsVSMPC.cpp:45-51 (beta1, beta2), :78-84, :156-159
@@ -684,6 +711,8 @@ void vsmpc_rollout_destroy(vsmpc_rollout* r) {
     if (r->d_ctl) (void)hipFree(r->d_ctl);
     if (r->d_rec) (void)hipFree(r->d_rec);
     if (r->d_tstate) (void)hipFree(r->d_tstate);
+    if (r->d_rs) (void)hipFree(r->d_rs);
+    if (r->d_ro) (void)hipFree(r->d_ro);
     if (r->gexec) (void)hipGraphExecDestroy(r->gexec);
     if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
     delete r;
@@ -699,8 +728,10 @@ int vsmpc_rollout_reset(vsmpc_rollout* r, const double* state, const double* par
     r->ticks_done = 0;
     // record of tick 0; from here on every tick's advance kernel leaves the record of the following tick
     r->valid = 0;
+    if (r->use_tree) HIP_TRY(enqueue_tree(r, nullptr, nullptr, nullptr));
     HIP_TRY(launch_record(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, r->d_tpos, r->d_tvel, r->d_talpha,
                           r->d_tstate, r->d_rec, nullptr));
+    if (r->use_tree) HIP_TRY(enqueue_tree_lambda(r, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     r->valid = 1;
     return VSMPC_OK;
@@ -732,6 +763,34 @@ int vsmpc_rollout_set_attitude_tracks(vsmpc_rollout* r, const double* traj_rpy, 
     const hipError_t e1 = set(r->d_trpyd, traj_rpy_dot);
     r->rd.traj_rpyd = r->d_trpyd;
     HIP_TRY(e1);
+    return VSMPC_OK;
+}
+
+int vsmpc_rollout_set_tree(vsmpc_rollout* r, const vsmpc_tree* tree) {
+    if (r == nullptr) return VSMPC_ERR_INVALID_ARG;
+    ON_DEVICE(r->h->device);
+    if (r->gexec) { (void)hipGraphExecDestroy(r->gexec); r->gexec = nullptr; }   // the captured ticks have other launches
+    r->graph_state = 0;
+    r->valid = 0;                                                                // vsmpc_rollout_reset before the next run
+    r->use_tree = 0;
+    r->rd.tree = 0;
+    if (tree == nullptr) return VSMPC_OK;
+    if (tree->parent[0] != -1) return VSMPC_ERR_INVALID_ARG;
+    for (int b = 1; b < VSMPC_TREE_NB; ++b)
+        if (tree->parent[b] < 0 || tree->parent[b] >= b) return VSMPC_ERR_INVALID_ARG;
+    for (int j = 0; j < VSMPC_TREE_NJ; ++j)
+        if (tree->robot_joint[j] < 0 || tree->robot_joint[j] >= VSMPC_KIN_NJ) return VSMPC_ERR_INVALID_ARG;
+    for (int i = 0; i < VSMPC_N_THRUSTS; ++i)
+        if (tree->jet_body[i] < 0 || tree->jet_body[i] >= VSMPC_TREE_NB) return VSMPC_ERR_INVALID_ARG;
+    const size_t B = size_t(r->batch);
+    if (r->d_rs == nullptr) HIP_TRY(hipMalloc(&r->d_rs, B * VSMPC_RS_SIZE * sizeof(double)));
+    if (r->d_ro == nullptr) HIP_TRY(hipMalloc(&r->d_ro, B * VSMPC_RO_SIZE * sizeof(double)));
+    r->tree = *tree;
+    r->use_tree = 1;
+    r->rd.tree = 1;
+    r->rd.tree_ro = r->d_ro;
+    r->rd.tree_kout = r->h->d_kout;
+    r->rd.tree_kin = r->h->d_kin;
     return VSMPC_OK;
 }
 
@@ -769,9 +828,11 @@ hipError_t enqueue_tick(vsmpc_rollout* r, hipStream_t s) {
     vsmpc_handle* h = r->h;
     hipError_t e = launch_solve(h->variant, h->form, h->dev, r->d_rec, r->batch, h->d_x, h->d_fm, h->d_status, h->d_iters, nullptr,
                                 nullptr, nullptr, s);
+    if (e == hipSuccess && r->use_tree) e = enqueue_tree(r, h->d_fm, h->d_status, s);   // A_mom, I_B of the joints after the move
     if (e == hipSuccess)
         e = launch_advance(r->rd, r->batch, r->d_state, r->d_params, r->d_tick, h->d_fm, h->d_status, h->d_iters,
                            r->d_talpha, r->d_ctl, r->substeps, r->d_tpos, r->d_tvel, r->d_tstate, r->d_rec, s);
+    if (e == hipSuccess && r->use_tree) e = enqueue_tree_lambda(r, s);
     return e;
 }
 

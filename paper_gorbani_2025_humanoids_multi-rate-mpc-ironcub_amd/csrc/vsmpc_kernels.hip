@@ -3181,7 +3181,7 @@ __global__ __launch_bounds__(64) void kinematics_kernel(const double* __restrict
         }
     }
     if (out != nullptr && lane < VSMPC_KIN_OUT) out[size_t(b) * VSMPC_KIN_OUT + lane] = res;
-    if (opts.records != nullptr && lane < VSMPC_KIN_OUT) {   // device-resident input records: LLIN | LANG | INERTIA
+    if (opts.records != nullptr && lane < (opts.skip_inertia ? 48 : VSMPC_KIN_OUT)) {   // device-resident input records: LLIN | LANG | INERTIA
         double* rec = opts.records + size_t(b) * opts.n_in;
         rec[(lane < 24 ? VSMPC_IN_LLIN + lane : (lane < 48 ? VSMPC_IN_LANG + lane - 24 : VSMPC_IN_INERTIA + lane - 48))] = res;
     }

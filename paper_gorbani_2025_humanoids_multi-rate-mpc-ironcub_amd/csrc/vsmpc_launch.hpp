@@ -47,6 +47,7 @@ struct KinOpts {
     int constant_lambda;       // jointsLambdaOption "constant"
     double* records = nullptr; // when set: LLIN | LANG | INERTIA are written into these device-resident input records
     int n_in = 0;
+    int skip_inertia = 0;      // patching only: leave INERTIA alone (the rollout's tree plant writes R I_B R^T itself)
 };
 hipError_t launch_kinematics(const double* d_kin, int batch, double* d_out, const KinOpts& opts, hipStream_t stream);
 
@@ -66,6 +67,14 @@ struct RolloutDev {
     const double* traj_rpy;      // device, [n_traj][3] or nullptr: RPY / RPYDot tracks of the position trajectory
     const double* traj_rpyd;     //   (vsmpc_rollout_set_attitude_tracks; the shipped ones are all zero)
     // jet plant option (vsmpc_rollout_set_jet_plant): LSTM thrust dynamics + EKF estimates instead of the polynomial model
+    // kinematic-tree plant (vsmpc_rollout_set_tree): A_mom,body(q), I_B(q) and the Lambda terms come from the kinematics
+    // provider evaluated on the plant's own joint state in the body frame (base at the origin, identity attitude), through
+    // these per-instance arrays: Robot-level outputs [batch][VSMPC_RO_SIZE], kinematics terms [batch][VSMPC_KIN_OUT] (I_G
+    // = I_B there), and the kinematics record [batch][VSMPC_KIN_SIZE] whose thrusts the advance kernel refreshes
+    int tree;
+    const double* tree_ro;
+    const double* tree_kout;
+    double* tree_kin;
     int jet_nn, jet_hidden;
     const float* jet_w;          // device: wih col 0 [4H] | wih col 1 [4H] | b_ih [4H] | b_hh [4H] | fc_w [H] | fc_b
     double jet_norm[4];          // thrust mean / std, throttle mean / std of the checkpoint
@@ -78,6 +87,10 @@ struct RolloutCtl {   // device-resident per-run control block of the rollout
     int tick_base;    // tick counter at the start of the run
     int log_rows;     // rows the log buffer holds
 };
+// provider state of every instance at the body-frame pose: joints = plant joints (+ the first move's increments when `fm`
+// is given and the status is Solved: what the advance kernel is about to apply), thrusts as the controller sees them
+hipError_t launch_tree_state(const RolloutDev& rd, int batch, const double* state, const double* fm, const int* status,
+                             double* rs, hipStream_t stream);
 hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,
                          const double* traj_pos, const double* traj_vel, const double* traj_alpha, double* tstate,
                          double* rec, hipStream_t stream);

@@ -111,10 +111,14 @@ VS_DEV double alpha_of_tick(const double* __restrict__ tr, int n, int up, int tk
 // `r` (LDS) by the 64 lanes of the workgroup; `ts` is advanced to "after update() number tk".  `first` builds the tick
 // state itself: what configure() leaves behind, fast-forwarded to tick `tk` for loops that start mid-trajectory (window
 // columns frozen with the current R, as if the attitude had been constant before).  Ends with a barrier.
+// Tree plant (rd.tree): IB = I_B(q) and amom = A_mom,body(q) of the kinematic tree (LDS copies of the provider's outputs for
+// this instance) take the place of the plant parameters; Lambda_lin / Lambda_ang are left to the kinematics kernel, which
+// patches them into the finished record from the tree's Jacobians and the thrusts the advance kernel measured.
 VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, const double* __restrict__ p, int tk,
                             const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
                             const double* __restrict__ traj_alpha, double* __restrict__ R, double* __restrict__ om,
-                            double* __restrict__ ts, double* __restrict__ r, int lane, bool first) {
+                            double* __restrict__ ts, double* __restrict__ r, int lane, bool first,
+                            const double* __restrict__ IB, const double* __restrict__ amom) {
     const double m = p[VSMPC_PP_MASS];
     const int nref = rd.n_ref, nwin = 12 * rd.n_ref;
     double* rpy_old = ts + nwin;
@@ -124,7 +128,7 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
         rot_from_rpy(s + VSMPC_PS_RPY, R);
     } else if (lane == 1) {
         double IBi[9];
-        inv3(p + VSMPC_PP_INERTIA_B, IBi);
+        inv3(IB, IBi);
         for (int i = 0; i < 3; ++i)
             om[i] = IBi[3 * i] * s[VSMPC_PS_HANG] + IBi[3 * i + 1] * s[VSMPC_PS_HANG + 1] + IBi[3 * i + 2] * s[VSMPC_PS_HANG + 2];
     } else if (lane >= 2 && lane < 5) {
@@ -163,7 +167,7 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
             for (int c = 0; c < 3; ++c) {
                 double rw = 0.0;
                 for (int j = 0; j < 3; ++j) rw += R[3 * j + c] * wd[j];     // (R^T wd)[c]
-                acc += R[3 * row + a] * p[VSMPC_PP_INERTIA_B + 3 * a + c] * rw;
+                acc += R[3 * row + a] * IB[3 * a + c] * rw;
             }
         return acc;
     };
@@ -202,7 +206,7 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
     if (lane < 24) {
         double acc = p[VSMPC_PP_AMOM0 + lane];
         for (int j = 0; j < 8; ++j) acc += p[VSMPC_PP_DJ + 24 * j + lane] * (s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j]);
-        r[VSMPC_IN_AMOM + lane] = acc;
+        r[VSMPC_IN_AMOM + lane] = rd.tree ? amom[lane] : acc;
     }
     // thrusts and thrust rates as the controller sees them: the plant's own with the polynomial jet plant, the EKF
     // estimates with the NN jet plant (the harness hands the estimate to Robot::setJetThrusts)
@@ -212,6 +216,7 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
         const int row = lane >> 3, j = lane & 7;   // row 0..5 of DJ[j] T
         double acc = 0.0;
         for (int c = 0; c < 4; ++c) acc += p[VSMPC_PP_DJ + 24 * j + 4 * row + c] * meas_T(c);
+        if (rd.tree) acc = 0.0;   // (patched in afterwards by the kinematics kernel)
         if (row < 3) r[VSMPC_IN_LLIN + 8 * row + j] = acc;
         else r[VSMPC_IN_LANG + 8 * (row - 3) + j] = acc;
     }
@@ -219,7 +224,7 @@ VS_DEV void assemble_record(const RolloutDev& rd, const double* __restrict__ s, 
         const int i = (lane - 48) / 3, j = (lane - 48) % 3;
         double acc = 0.0;
         for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 3; ++c) acc += R[3 * i + a] * p[VSMPC_PP_INERTIA_B + 3 * a + c] * R[3 * j + c];
+            for (int c = 0; c < 3; ++c) acc += R[3 * i + a] * IB[3 * a + c] * R[3 * j + c];
         r[VSMPC_IN_INERTIA + 3 * i + j] = acc;
     }
     // X0 (constraintsVSMPC.cpp:206-230): RPY enters unwrapped
@@ -262,14 +267,19 @@ __global__ __launch_bounds__(RO_BLOCK) void record_kernel(RolloutDev rd, int bat
                                                            const double* __restrict__ traj_pos, const double* __restrict__ traj_vel,
                                                            const double* __restrict__ traj_alpha, double* __restrict__ tstate,
                                                            double* __restrict__ rec) {
-    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], R[9], om[3];
+    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], R[9], om[3], tIB[9], tAm[24];
     __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES], ts[12 * MAX_STAGES + 8];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= batch) return;
     stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
     stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
+    if (rd.tree) {
+        if (lane < 9) tIB[lane] = rd.tree_kout[size_t(b) * VSMPC_KIN_OUT + 48 + lane];
+        if (lane >= 32 && lane < 56) tAm[lane - 32] = rd.tree_ro[size_t(b) * VSMPC_RO_SIZE + VSMPC_RO_AMOMB + lane - 32];
+    }
     __syncthreads();
-    assemble_record(rd, s, p, tick[b] + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, true);
+    assemble_record(rd, s, p, tick[b] + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, true,
+                    rd.tree ? tIB : p + VSMPC_PP_INERTIA_B, tAm);
     double* out = rec + size_t(b) * rd.n_in;
     for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
     double* tso = tstate + size_t(b) * rd.n_ts;
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
                                                             const double* __restrict__ traj_pos,
                                                             const double* __restrict__ traj_vel, double* __restrict__ tstate,
                                                             double* __restrict__ rec_next) {
-    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9], R[9], om[3];
+    __shared__ double s[VSMPC_PLANT_STATE], p[VSMPC_PLANT_PARAMS + 1], f[VSMPC_FM_SIZE], Aq[24], IBi[9], R[9], om[3], tIB[9];
     __shared__ double r[VSMPC_IN_XREF + 12 * MAX_STAGES], ts[12 * MAX_STAGES + 8];
     __shared__ float jw[17 * JET_HMAX + 1];   // LSTM weights of the jet plant option
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -298,6 +308,9 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
     stage_in<VSMPC_PLANT_STATE>(state + size_t(b) * VSMPC_PLANT_STATE, s, lane);
     stage_in<VSMPC_PLANT_PARAMS>(params + size_t(b) * VSMPC_PLANT_PARAMS, p, lane);
     stage_in<VSMPC_FM_SIZE>(fm + size_t(b) * VSMPC_FM_SIZE, f, lane);
+    if (rd.tree && lane < 9) tIB[lane] = rd.tree_kout[size_t(b) * VSMPC_KIN_OUT + 48 + lane];   // I_B(q) of the tree, q = the joints
+    double tree_amom = 0.0;                                                                     // AFTER this tick's move
+    if (rd.tree && lane < 24) tree_amom = rd.tree_ro[size_t(b) * VSMPC_RO_SIZE + VSMPC_RO_AMOMB + lane];
     const int st = status[b];
     const int tick_before = tick[b];
     // every global load of this kernel is requested as early as possible: each dependent round trip costs ~1.5 us
@@ -323,9 +336,9 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
     if (lane < 24) {  // A_mom(q): the joints only move at the tick boundary
         double acc = p[VSMPC_PP_AMOM0 + lane];
         for (int j = 0; j < 8; ++j) acc += p[VSMPC_PP_DJ + 24 * j + lane] * (s[VSMPC_PS_Q + j] - p[VSMPC_PP_QREF0 + j]);
-        Aq[lane] = acc;
+        Aq[lane] = rd.tree ? tree_amom : acc;
     } else if (lane == 24) {
-        inv3(p + VSMPC_PP_INERTIA_B, IBi);
+        inv3(rd.tree ? tIB : p + VSMPC_PP_INERTIA_B, IBi);
     }
     __syncthreads();
     // explicit Euler sub-steps, one state component per lane (20 lanes): the three sincos run side by side in lanes
@@ -445,13 +458,40 @@ __global__ __launch_bounds__(RO_BLOCK) void advance_kernel(RolloutDev rd, int ba
         // workgroup here: the record of the next tick is assembled below, with barriers)
         if (row >= 0 && row < log_rows) log[(size_t(row) * batch + b) * VSMPC_ROLLOUT_LOG + lane] = v;
     }
+    if (rd.tree && lane < 4)   // the thrusts the next tick's Lambda terms are formed with (kinematics kernel, next launch)
+        rd.tree_kin[size_t(b) * VSMPC_KIN_SIZE + VSMPC_KIN_THRUST + lane] = rd.jet_nn ? s[VSMPC_PS_EST + 2 * lane] : s[VSMPC_PS_T + lane];
     if (rec_next != nullptr) {
-        assemble_record(rd, s, p, tick_before + 1 + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, false);
+        assemble_record(rd, s, p, tick_before + 1 + int(p[VSMPC_PP_TICK0]), traj_pos, traj_vel, traj_alpha, R, om, ts, r, lane, false,
+                        rd.tree ? tIB : p + VSMPC_PP_INERTIA_B, Aq);
         double* out = rec_next + size_t(b) * rd.n_in;
         for (int e = lane; e < rd.n_in; e += RO_BLOCK) out[e] = r[e];
         double* tso = tstate + size_t(b) * rd.n_ts;
         for (int e = lane; e < rd.n_ts; e += RO_BLOCK) tso[e] = ts[e];
     }
+}
+
+// Provider state of the tree plant, one thread per instance: the base frame is the body frame (origin, identity attitude,
+// at rest), so that every output of the provider is a body-frame quantity of the joints alone -- A_mom,body(q), the
+// Jacobians behind Lambda_lin,B / Lambda_ang,B (systemDynamicsVSMPC.cpp:159-226,321-350 are body-frame expressions) and
+// I_B(q).  The joints are the plant's, plus this tick's increments when the solve succeeded (variableSamplingMPC.cpp:
+// 104-108): the advance kernel applies the same move and integrates with the A_mom and I_B of the moved joints.
+__global__ void tree_state_kernel(RolloutDev rd, int batch, const double* __restrict__ state, const double* __restrict__ fm,
+                                  const int* __restrict__ status, double* __restrict__ rs) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* s = state + size_t(b) * VSMPC_PLANT_STATE;
+    double* o = rs + size_t(b) * VSMPC_RS_SIZE;
+    for (int i = 0; i < VSMPC_RS_SIZE; ++i) o[i] = 0.0;
+    o[VSMPC_RS_R + 0] = 1.0; o[VSMPC_RS_R + 4] = 1.0; o[VSMPC_RS_R + 8] = 1.0;
+    const bool move = fm != nullptr && status[b] == VSMPC_STATUS_SOLVED;
+    for (int j = 0; j < 8; ++j) o[VSMPC_RS_Q + j] = s[VSMPC_PS_Q + j] + (move ? fm[size_t(b) * VSMPC_FM_SIZE + VSMPC_FM_DQ + j] : 0.0);
+    for (int i = 0; i < 4; ++i) o[VSMPC_RS_T + i] = rd.jet_nn ? s[VSMPC_PS_EST + 2 * i] : s[VSMPC_PS_T + i];
+}
+
+hipError_t launch_tree_state(const RolloutDev& rd, int batch, const double* state, const double* fm, const int* status,
+                             double* rs, hipStream_t stream) {
+    hipLaunchKernelGGL(tree_state_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, rd, batch, state, fm, status, rs);
+    return hipGetLastError();
 }
 
 hipError_t launch_record(const RolloutDev& rd, int batch, const double* state, const double* params, const int* tick,

@@ -117,6 +117,26 @@ def make_plant(cfg: L.MPCConfig, batch: int, *, workload: str = "hover", seed0: 
     return state, params
 
 
+def make_plant_tree(cfg: L.MPCConfig, batch: int, tree: dict, *, workload: str = "hover", seed0: int = 4321, first_index: int = 0):
+    """Plant states / parameters for the KINEMATIC-TREE plant (ClosedLoopRollout.set_tree): make_plant's instances with the
+    tree's total mass, joints at zero and initial thrusts that carry that mass; AMOM0 / DJ / INERTIA_B stay in the
+    parameter record but are not read in tree mode (A_mom(q), I_B(q), Lambda come from the provider on the plant's joints)."""
+    state, params = make_plant(cfg, batch, workload=workload, seed0=seed0, first_index=first_index)
+    m_tree = float(np.float32(sum(tree["mass"])))
+    for b in range(batch):
+        scale = m_tree / params[b, L.PP_MASS]
+        params[b, L.PP_MASS] = m_tree
+        state[b, L.PS_HLIN:L.PS_HLIN + 3] *= scale
+        T = state[b, L.PS_T:L.PS_T + 4] * scale
+        u = np.clip([float(_JET.steady_state_throttle(Ti)) for Ti in T], 0.0, 100.0)
+        state[b, L.PS_T:L.PS_T + 4] = T
+        state[b, L.PS_U:L.PS_U + 4] = u
+        state[b, L.PS_TDES:L.PS_TDES + 4] = T
+        state[b, L.PS_TNN:L.PS_TNN + 4] = np.asarray(T, dtype=np.float32)
+        state[b, L.PS_EST:L.PS_EST + 8:2] = T
+    return state, params
+
+
 def make_trajectory(cfg: L.MPCConfig, workload: str = "hover", horizon_s: float = 60.0):
     """(pos[n,3], vel[n,3], alpha[m], alpha_dt): CoM offsets / velocities sampled every periodMPCLargeSteps and the
     alpha-gravity profile sampled at 10 Hz, the rates of the reference's MAT trajectories."""
@@ -192,6 +212,15 @@ class ClosedLoopRollout:
             if t is not None and t.shape != (self.n_traj, 3):
                 raise ValueError(f"attitude tracks must be [{self.n_traj}, 3]")
         _lib.check(self.lib.vsmpc_rollout_set_attitude_tracks(self._r, _ptr(a), _ptr(b)), "vsmpc_rollout_set_attitude_tracks")
+
+    def set_tree(self, tree: dict | None):
+        """Kinematic-tree plant (vsmpc_rollout_set_tree): `tree` = a robot_tree dictionary (None = the parametric plant).
+        The plant's A_mom(q), I_B(q) and the MPC's Lambda terms then all come from the kinematics provider on the plant's
+        own joints.  Call reset() afterwards; params[:, PP_MASS] must be the tree's total mass."""
+        from . import robot_tree as RT
+        self._ctree = None if tree is None else RT.to_c(tree)    # (kept alive; the library copies it anyway)
+        _lib.check(self.lib.vsmpc_rollout_set_tree(self._r, None if tree is None else ctypes.byref(self._ctree)),
+                   "vsmpc_rollout_set_tree")
 
     def set_jet_plant(self, jet_model=None, Q=None, R=None):
         """Jet plant option (vsmpc_rollout_set_jet_plant): `jet_model` = a jet_plant.JetModelTotal (the LSTM thrust model;

@@ -42,18 +42,34 @@ def period_map(cfg, rcfg, ref, rm, s, p, traj, start_tick=0):
     return s
 
 
-def monodromy(seed0=4321, eps=1e-6):
+def tree_plant(seed0=4321):
+    """One hover instance of the KINEMATIC-TREE plant (vsmpc_rollout_set_tree): the parametric instance of that seed with
+    the tree's mass, started with the thrusts that carry it"""
+    layout = importlib.import_module(PKG + ".layout")
+    ro = importlib.import_module(PKG + ".rollout")
+    RT = importlib.import_module(PKG + ".robot_tree")
+    cfg = layout.paper_config()
+    st, pa = ro.make_plant_tree(cfg, 1, RT.default_tree(), workload="hover", seed0=seed0)
+    return RT.default_tree(), st, pa
+
+
+def monodromy(seed0=4321, eps=1e-6, tree=False, settle=30):
     import rollout_model as rm
     import vsmpc_ref as ref
     layout = importlib.import_module(PKG + ".layout")
     ro = importlib.import_module(PKG + ".rollout")
     cfg, rcfg = layout.paper_config(), ref.paper_config()
-    st, pa = ro.make_plant(cfg, 1, workload="hover", seed0=seed0)
+    if tree:
+        tr, st, pa = tree_plant(seed0)
+        rm.set_tree(tr)
+    else:
+        rm.set_tree(None)
+        st, pa = ro.make_plant(cfg, 1, workload="hover", seed0=seed0)
     traj = ro.make_trajectory(cfg, "hover", 5.0)
     p = pa[0].copy()
     # settle onto the periodic orbit near hover first (a few periods), then linearise about that point
     s = st[0].copy()
-    for _ in range(30):
+    for _ in range(settle):
         s = period_map(cfg, rcfg, ref, rm, s, p, traj)
     n = N_LIN
     f0 = period_map(cfg, rcfg, ref, rm, s, p, traj)
@@ -96,10 +112,11 @@ def setup(seed0=4321):
 
 
 FIXTURE = os.path.join(ROOT, "tests", "golden", "hover_monodromy.npz")
+FIXTURE_TREE = os.path.join(ROOT, "tests", "golden", "hover_monodromy_tree.npz")
 
 
-def load_fixture():
-    d = np.load(FIXTURE)
+def load_fixture(tree=False):
+    d = np.load(FIXTURE_TREE if tree else FIXTURE)
     return d["M"], d["orbit"], float(d["rho"])
 
 
@@ -110,11 +127,13 @@ def spectral_radius(M):
 if __name__ == "__main__":
     import time
     t = time.time()
-    M, s, f0 = monodromy()
+    use_tree = "--tree" in sys.argv
+    settle = int(sys.argv[sys.argv.index("--settle") + 1]) if "--settle" in sys.argv else 30
+    M, s, f0 = monodromy(tree=use_tree, settle=settle)
     ev = np.linalg.eigvals(M)
     print("residual of the orbit:", np.abs(f0 - s).max())
     print("spectral radius per hold period (0.1 s):", np.abs(ev).max(), " time %.0f s" % (time.time() - t))
     print(np.sort(np.abs(ev))[::-1][:10])
     if "--write" in sys.argv:
-        np.savez(FIXTURE, M=M, orbit=s, rho=np.abs(ev).max(), seed0=4321, eps=1e-6)
-        print("wrote", FIXTURE)
+        np.savez(FIXTURE_TREE if use_tree else FIXTURE, M=M, orbit=s, rho=np.abs(ev).max(), seed0=4321, eps=1e-6, settle=settle)
+        print("wrote", FIXTURE_TREE if use_tree else FIXTURE)

@@ -32,7 +32,37 @@ def interp_clamped(tr, pos):
     return tr[i] + (pos - i) * (tr[i + 1] - tr[i])
 
 
+_TREE = None   # kinematic-tree plant (vsmpc_rollout_set_tree): a robot_tree dictionary, or None for the parametric plant
+
+
+def set_tree(tree):
+    """Selects the plant: with a tree, A_mom,body(q), I_B(q) and the Lambda terms come from the kinematics oracle
+    (oracle/robot_tree_ref.py + vsmpc_ref.kinematics_terms) on the plant's own joints in the body frame, which is what the
+    device does with the provider / kinematics kernels; PP_AMOM0 / PP_DJ / PP_INERTIA_B are not read."""
+    global _TREE
+    _TREE = tree
+
+
+def tree_terms(q, T):
+    """(A_mom,body 6x4, Lambda 6x8 at thrusts T, I_B 3x3) of the tree at joints q: base at the origin, identity attitude"""
+    import robot_tree_ref as rt
+    import vsmpc_ref as ref
+    st = dict(p_base=np.zeros(3), R_base=np.eye(3), v_base=np.zeros(3), w_base=np.zeros(3), q=np.asarray(q, float),
+              qd=np.zeros(8), thrust=np.asarray(T, float))
+    o = rt.forward(_TREE, st)
+    llin, lang, ib = ref.kinematics_terms(rt.kin_record(o, st, L))
+    return o["Amom_body"], np.vstack([llin, lang]), ib
+
+
+def inertia_body(s, p):
+    if _TREE is not None:
+        return tree_terms(s[L.PS_Q:L.PS_Q + 8], s[L.PS_T:L.PS_T + 4])[2]
+    return p[L.PP_INERTIA_B:L.PP_INERTIA_B + 9].reshape(3, 3)
+
+
 def amom_of_q(s, p):
+    if _TREE is not None:
+        return tree_terms(s[L.PS_Q:L.PS_Q + 8], s[L.PS_T:L.PS_T + 4])[0], None
     A = p[L.PP_AMOM0:L.PP_AMOM0 + 24].reshape(6, 4).copy()
     DJ = p[L.PP_DJ:L.PP_DJ + 192].reshape(8, 6, 4)
     dq = s[L.PS_Q:L.PS_Q + 8] - p[L.PP_QREF0:L.PP_QREF0 + 8]
@@ -46,7 +76,7 @@ def kin_record(cfg, s, p):
     tests/tick_model.py, which is written from the reference's plugins."""
     rec = np.zeros(cfg.n_in)
     R = rot(s[L.PS_RPY:L.PS_RPY + 3])
-    IB = p[L.PP_INERTIA_B:L.PP_INERTIA_B + 9].reshape(3, 3)
+    IB = inertia_body(s, p)
     omega = np.linalg.solve(IB, s[L.PS_HANG:L.PS_HANG + 3])
     rec[L.IN_MASS] = p[L.PP_MASS]
     rec[L.IN_WRB:L.IN_WRB + 9] = R.reshape(-1)
@@ -54,7 +84,7 @@ def kin_record(cfg, s, p):
     rec[L.IN_GRAV:L.IN_GRAV + 3] = [0.0, 0.0, -9.81]
     A, DJ = amom_of_q(s, p)
     T = s[L.PS_T:L.PS_T + 4]
-    Lam = np.einsum("jrc,c->rj", DJ, T)           # 6 x 8
+    Lam = tree_terms(s[L.PS_Q:L.PS_Q + 8], T)[1] if _TREE is not None else np.einsum("jrc,c->rj", DJ, T)   # 6 x 8
     rec[L.IN_AMOM:L.IN_AMOM + 24] = A.reshape(-1)
     rec[L.IN_LLIN:L.IN_LLIN + 24] = Lam[0:3].reshape(-1)
     rec[L.IN_LANG:L.IN_LANG + 24] = Lam[3:6].reshape(-1)
@@ -102,7 +132,7 @@ def advance(cfg, s, p, tick, fm, status, traj_alpha, alpha_dt, substeps=5, jet=N
         s[L.PS_TDDES:L.PS_TDDES + 4] = fm[L.FM_THRUSTDOT:L.FM_THRUSTDOT + 4]
     tk = tick + int(p[L.PP_TICK0])
     m = p[L.PP_MASS]
-    IB = p[L.PP_INERTIA_B:L.PP_INERTIA_B + 9].reshape(3, 3)
+    IB = inertia_body(s, p)            # (the joints only move at the tick boundary: constant over the sub-steps)
     A, _ = amom_of_q(s, p)
     vthr = np.array([_JET.compute_v(_JET.standardizeThrottle_u2T(u)) for u in s[L.PS_U:L.PS_U + 4]])
     sg = _JET.getThrustStandardDeviation_u2T()

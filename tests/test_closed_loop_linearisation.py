@@ -67,3 +67,31 @@ def test_the_marginal_modes_are_the_ones_the_cost_does_not_see():
     # matter of the synthetic jet geometry, not of the loop
     hlx_pairs = [abs(w[k]) for k in range(len(w)) if lead_of[k] == layout.PS_HLIN and abs(w[k].imag) > 0.1 and abs(w[k]) > 0.9]
     assert hlx_pairs and max(hlx_pairs) < 1.0
+
+
+def test_tree_plant_fixture_matches_a_fresh_derivation():
+    """The same linearisation on the KINEMATIC-TREE plant (vsmpc_rollout_set_tree; tests/closed_loop_linearisation.py --tree
+    --settle 100): the plant whose Lambda is its own kinematics.  Two columns recomputed from scratch, and the structure of
+    the spectrum: the lateral-momentum / arm-jet thrust-rate pair still leads, at 1.0022 per hold period instead of 1.0062."""
+    import importlib
+    import rollout_model as rm
+    M, orbit, rho = cl.load_fixture(tree=True)
+    layout = importlib.import_module("paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd.layout")
+    cfg, rcfg, ref, _, _, _, _, traj = cl.setup()
+    tr, st, pa = cl.tree_plant()
+    rm.set_tree(tr)
+    try:
+        p = pa[0].copy()
+        scale = cl.fd_scale(layout)
+        for i in (layout.PS_HLIN + 1, layout.PS_Q + 2):
+            col = cl.column(cfg, rcfg, ref, rm, orbit, p, traj, i, 1e-6 * scale[i])
+            np.testing.assert_allclose(col, M[:, i], rtol=1e-5, atol=1e-7)
+    finally:
+        rm.set_tree(None)
+    assert abs(cl.spectral_radius(M) - rho) < 1e-12 and 1.0 < rho < 1.003
+    w, V = np.linalg.eig(M)
+    lead = int(np.argmax(np.abs(w)))
+    v = np.abs(V[:, lead]) / np.abs(V[:, lead]).max()
+    assert abs(w[lead].imag) > 0.1 and v[layout.PS_HLIN + 1] == 1.0                      # lateral momentum ...
+    assert v[layout.PS_TD] > 0.4 and v[layout.PS_TD + 1] > 0.4                           # ... against the arm jets' thrust rates
+    assert 2.0 < 2 * np.pi / abs(np.angle(w[lead])) * 0.1 < 3.5                          # period in seconds

@@ -340,3 +340,112 @@ def test_montecarlo_rollout_recovers_from_disturbances(ro, layout):
     assert ez.max() < 6.0 and np.abs(log[:, :, 3:6]).max() < 1.0   # bounded excursion
     assert np.median(ez[-1]) < 0.25 and ez[-1].max() < 1.2         # recovered
     assert np.median(ez[-1]) < 0.5 * np.median(ez[400])            # and much better than at the 2 s mark
+
+
+def test_tree_plant_matches_model(ro, layout):
+    """N2 inside N1 (vsmpc_rollout_set_tree): the plant's joint vectoring is the kinematics the MPC linearises -- every tick
+    the provider / kinematics kernels are evaluated on the plant's own joints (src/mujoco_lib/ironcub_mujoco_simulator.py:
+    318-346 -> utils/src/Robot.cpp:198-335 in the harness), and A_mom,body(q), I_B(q), Lambda_lin / Lambda_ang replace the
+    plant parameters.  Records and plant states against the numpy model on oracle/robot_tree_ref.py + the oracle's
+    kinematics terms over eight ticks (the joints move every tick), a graph-replayed chunk of 30 ticks against the same
+    model, then the parametric plant again."""
+    RT = importlib.import_module(PKG + ".robot_tree")
+    tree = RT.default_tree()
+    cfg = layout.paper_config()
+    B = 6
+    st, pa = ro.make_plant_tree(cfg, B, tree, workload="montecarlo")
+    pos, vel, alpha, adt = ro.make_trajectory(cfg, "hover", 20.0)
+    r = ro.ClosedLoopRollout(cfg, B, pos, vel, alpha, adt, device=0)
+    try:
+        r.reset(st, pa)
+        r.set_tree(tree)
+        with pytest.raises(Exception):
+            r.run(1)                                           # the plant changed under the records: reset() first
+        r.reset(st, pa)
+        rm.set_tree(tree)
+        s_host = st.copy()
+        models = [rm.make_tick_model(cfg, st[b], pa[b], pos, vel, alpha) for b in range(B)]
+        recs = r.next_records()
+        moved = 0.0
+        for tick in range(8):
+            r.run(1, log=False)
+            x, fm, status, iters = r.mpc.solve(recs)
+            after = r.state()
+            for b in range(B):
+                rec_m = rm.build_record(cfg, models[b], s_host[b], pa[b])
+                assert relerr(recs[b], rec_m) < 1e-12, (tick, b, int(np.abs(recs[b] - rec_m).argmax()))
+                models[b].consume(fm[b], status[b])
+                s_m = rm.advance(cfg, s_host[b], pa[b], tick, fm[b], status[b], alpha, adt)
+                assert relerr(after[b], s_m) < 1e-11, (tick, b)
+            moved = max(moved, float(np.abs(after[:, layout.PS_Q:layout.PS_Q + 8]).max()))
+            recs = r.next_records()
+            s_host = after
+        assert (status == layout.STATUS_SOLVED).all() and moved > 1e-3        # the joints (and with them A_mom, Lambda) did move
+        # the record's Lambda is the tree's, not the parameter record's: column j = dA_mom/dq_j T would differ
+        lam = recs[0, layout.IN_LLIN:layout.IN_LLIN + 48]
+        assert np.abs(lam).max() > 1.0
+        # 30 more ticks replayed from the captured graph (25) + direct launches (5), against the model driven by the
+        # device's own first moves
+        for tick in range(8, 38):
+            x, fm, status, iters = r.mpc.solve(recs)
+            for b in range(B):
+                rm.build_record(cfg, models[b], s_host[b], pa[b])
+                models[b].consume(fm[b], status[b])
+                s_host[b] = rm.advance(cfg, s_host[b], pa[b], tick, fm[b], status[b], alpha, adt)
+            r.run(1, log=False)
+            recs = r.next_records()
+        r2 = ro.ClosedLoopRollout(cfg, B, pos, vel, alpha, adt, device=0)
+        try:
+            r2.set_tree(tree)
+            r2.reset(st, pa)
+            r2.run(38, log=False)                              # one call: graph replay
+            assert relerr(r2.state(), r.state()) < 1e-9
+            assert relerr(r.state(), s_host) < 1e-8
+        finally:
+            r2.close()
+        r.set_tree(None)                                       # back to the parametric plant
+        rm.set_tree(None)
+        r.reset(st, pa)
+        recs = r.next_records()
+        r.run(1, log=False)
+        _, fm, status, _ = r.mpc.solve(recs)
+        for b in range(B):
+            assert relerr(r.state()[b], rm.advance(cfg, st[b], pa[b], 0, fm[b], status[b], alpha, adt)) < 1e-12
+    finally:
+        rm.set_tree(None)
+        r.close()
+
+
+def test_tree_plant_hover_properties(ro, layout):
+    """64 hover loops on the kinematic-tree plant, 12 s (2400 ticks, graph-replayed): every solve optimal, the flight
+    settles onto the trimmed hover the oracle-in-the-loop model finds (joints move to ~0.4 rad to trim the tree's jet
+    geometry), attitude and position stay bounded.  The bound on the slow lateral mode comes from the linearised closed loop
+    on THIS plant (tests/golden/hover_monodromy_tree.npz: rho = 1.0022 per 0.1 s hold period -- the same lateral-momentum /
+    arm-jet thrust-rate pair as on the parametric plant, where it is 1.0062): the plant whose Lambda IS its kinematics
+    still has the marginal mode, so it belongs to the formulation (no weight on the thrust split, no roll -> lateral-force
+    model inside the horizon), not to an inconsistency of the synthetic plant."""
+    import closed_loop_linearisation as cl
+    RT = importlib.import_module(PKG + ".robot_tree")
+    tree = RT.default_tree()
+    cfg = layout.paper_config()
+    B, T = 64, 2400
+    st, pa = ro.make_plant_tree(cfg, B, tree, workload="hover")
+    pos, vel, alpha, adt = ro.make_trajectory(cfg, "hover", 30.0)
+    r = ro.ClosedLoopRollout(cfg, B, pos, vel, alpha, adt, device=0)
+    try:
+        r.set_tree(tree)
+        r.reset(st, pa)
+        log = r.run(T)
+        final = r.state()
+    finally:
+        r.close()
+    assert np.isfinite(log).all() and (log[:, :, 14] == 1).all()
+    p_err = np.abs(log[:, :, 0:3] - pa[None, :, layout.PP_PINIT:layout.PP_PINIT + 3])
+    assert p_err.max() < 0.8 and np.median(p_err[-400:].max(axis=(0, 2))) < 0.25
+    assert np.abs(log[:, :, 3:6] - pa[None, :, layout.PP_RPYINIT:layout.PP_RPYINIT + 3]).max() < 0.35
+    assert (final[:, layout.PS_T:layout.PS_T + 4] > 50).all() and (final[:, layout.PS_T:layout.PS_T + 4] < 260).all()
+    assert np.abs(final[:, layout.PS_Q:layout.PS_Q + 8]).max() < 1.2          # the trim, not a wind-up
+    M, orbit, rho = cl.load_fixture(tree=True)
+    assert abs(cl.spectral_radius(M) - rho) < 1e-12 and rho < 1.003
+    # the loop ends near the model's orbit point (taken after 10 s of the oracle-in-the-loop model on seed 4321 = instance 0)
+    assert np.abs(final[0, layout.PS_Q:layout.PS_Q + 8] - orbit[layout.PS_Q:layout.PS_Q + 8]).max() < 0.15
