@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libvsmpc.so")
 SOURCES = ["vsmpc_kernels.hip", "vsmpc_rollout.hip", "vsmpc_capi.hip", "vsmpc_jet.hip", "vsmpc_provider.hip"]
-HEADERS = ["vsmpc_device.hpp", "vsmpc_launch.hpp", "vsmpc_jet_device.hpp", "vsmpc_horizons.def", os.path.join("..", "..", "include", "vsmpc.h"),
+HEADERS = ["vsmpc_device.hpp", "vsmpc_launch.hpp", "vsmpc_panel_asm.inc", "vsmpc_jet_device.hpp", "vsmpc_horizons.def", os.path.join("..", "..", "include", "vsmpc.h"),
            os.path.join("..", "..", "include", "vsmpc_jet.h")]
 
 

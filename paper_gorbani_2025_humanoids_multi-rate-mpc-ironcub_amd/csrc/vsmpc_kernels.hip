@@ -253,28 +253,29 @@ VS_DEV void p0_linearize(int use_jet, const double* __restrict__ sIn, double* __
     }
     // The independent pieces run in different wavefronts (0: attitude kinematics, 1: jets, 2: CoM / gravity, 2-3: copies)
     // so that their divergent paths overlap instead of serialising inside one wavefront; needs >= 256 threads.
-    if (tid == 0) {
+    if (tid < 64) {
         // A[rpy, angMom] = W(rpy)^-1 * I_G^-1                       (systemDynamicsVSMPC.cpp:86-87,140-147)
+        // One wavefront: even lanes take sin / cos of the roll, odd lanes of the pitch (ONE sincos instead of two in a row:
+        // it is the longest dependent chain of P0), lanes 0..8 then form one entry (i, j) each.
         const double* I = sIn + VSMPC_IN_INERTIA;
         const double a = I[0], b = I[1], c = I[2], d = I[3], e = I[4], f = I[5], g = I[6], h = I[7], k = I[8];
+        double sn, cs;
+        sincos(sIn[VSMPC_IN_RPY + (tid & 1)], &sn, &cs);
         const double A00 = e * k - f * h, A01 = c * h - b * k, A02 = b * f - c * e;
         const double A10 = f * g - d * k, A11 = a * k - c * g, A12 = c * d - a * f;
         const double A20 = d * h - e * g, A21 = b * g - a * h, A22 = a * e - b * d;
         const double idet = fast_rcp(a * A00 + b * A10 + c * A20);
-        const double Ii[9] = {A00 * idet, A01 * idet, A02 * idet, A10 * idet, A11 * idet,
-                              A12 * idet, A20 * idet, A21 * idet, A22 * idet};
-        const double r = sIn[VSMPC_IN_RPY + 0], p = sIn[VSMPC_IN_RPY + 1];
-        double sr, cr, sp, cp;
-        sincos(r, &sr, &cr);
-        sincos(p, &sp, &cp);
+        const double sr = readlane_f64(sn, 0), cr = readlane_f64(cs, 0), sp = readlane_f64(sn, 1), cp = readlane_f64(cs, 1);
         const double icp = fast_rcp(cp), tp = sp * icp;
-        const double Wi[9] = {1.0, sr * tp, cr * tp, 0.0, cr, -sr, 0.0, sr * icp, cr * icp};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double s = 0.0;
-                for (int q = 0; q < 3; ++q) s += Wi[3 * i + q] * Ii[3 * q + j];
-                sA[(6 + i) * NX + 9 + j] = s;
-            }
+        const int i = tid / 3, j = tid - 3 * i;                      // entry (i, j), tid < 9
+        // row i of W^-1 = [1, sr tp, cr tp; 0, cr, -sr; 0, sr / cp, cr / cp], column j of I^-1 = adj[:, j] / det
+        const double w0 = i == 0 ? 1.0 : 0.0;
+        const double w1 = i == 0 ? sr * tp : (i == 1 ? cr : sr * icp);
+        const double w2 = i == 0 ? cr * tp : (i == 1 ? -sr : cr * icp);
+        const double c0 = j == 0 ? A00 : (j == 1 ? A01 : A02);
+        const double c1 = j == 0 ? A10 : (j == 1 ? A11 : A12);
+        const double c2 = j == 0 ? A20 : (j == 1 ? A21 : A22);
+        if (tid < 9) sA[(6 + i) * NX + 9 + j] = (w0 * c0 + w1 * c1 + w2 * c2) * idet;
     } else if (tid >= 64 && tid < 68) {
         // jets                                                      (systemDynamicsVSMPC.cpp:384-429)
         const int i = tid - 64;
@@ -664,6 +665,54 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
     return !(dmin > 0.0) || !(inv_last == inv_last);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The panel streams as hand-scheduled assembly with DPP broadcasts (kernel v26; tools/gen_panel_asm.py has the why: a lone
+// wavefront issues one FP64 instruction per ~5.5 cycles whatever the dependencies, so a stream costs its instruction
+// count, and v_fmac_f64 with DPP row_newbcast needs two instructions per updated column where v_readlane needs three).
+// Lane 16 r + c of wavefront w carries panel row 16 p + 16 + 64 w + 16 r + c -- all 64 lanes carry rows BELOW the diagonal
+// tile -- and, in a second set of registers, row c of the diagonal tile, which every 16-lane row factors redundantly
+// (bit-identical in all rows and wavefronts).  Same arithmetic as panel_factor, operation by operation; in isolation
+// 2.7 k cycles against 3.9 k (tools/microbench/panel_probe.hip, profiles/r04_microbench_panel_probe.txt).
+// VS_PANEL_DPP=0 builds the C++ streams instead (A/B, and the reference the assembly is tested against).
+// ------------------------------------------------------------------------------------------------
+#ifndef VS_PANEL_DPP
+#define VS_PANEL_DPP 1
+#endif
+#include "vsmpc_panel_asm.inc"
+VS_DEV unsigned lds_addr(const double* q) { return unsigned(reinterpret_cast<uintptr_t>(q)); }   // flat -> LDS byte address
+
+// Shared panel p < NT - 1: rows 16 p + 16 + 64 w .. of the panel column; the factored diagonal tile comes back in `diag`
+// (lanes 0..15; stored by wavefront 0 after the barrier, the others read the unfactored tile meanwhile) and 1 / L_jj goes
+// to sInvD from wavefront 0.  `scratch` = 32 doubles of this wavefront nobody reads: rows beyond the matrix and the other
+// wavefronts' 1 / L_jj end there.  Returns non-zero if a pivot was not positive (its reciprocal square root is NaN, and
+// then so is everything after it down to the last one).
+template <class D>
+VS_DEV int panel_dpp(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16],
+                      double* scratch) {
+    const int r = 16 * p + 16 + 64 * w + lane;
+    const bool ok = r < D::NP;
+    const unsigned ld = lds_addr(Lb + tile_off<D>(ok ? (r >> 4) : p, p) + (r & 15) * 17);
+    double inv_last;
+    panel16_dpp(ld, ok ? ld : lds_addr(scratch), lds_addr(Lb + tile_off<D>(p, p) + (lane & 15) * 17),
+                lds_addr(w == 0 ? sInvD + 16 * p : scratch + 16), diag, inv_last);
+    return !(inv_last == inv_last);
+}
+// The last panel (one wavefront): NPIV pivots, the remaining rows of the tile (gradient row, padding) are ordinary rows.
+template <class D, int NPIV>
+VS_DEV int panel_last_dpp(double* __restrict__ Lb, double* __restrict__ sInvD, int lane) {
+    constexpr int p = D::NT - 1;
+    double g[16], inv_last;
+    double* T = Lb + tile_off<D>(p, p) + (lane & 15) * 17;
+    static_assert(NPIV == 8 || NPIV == 12, "tools/gen_panel_asm.py LAST_PANEL_PIVOTS");
+    if constexpr (NPIV == 8) panel_last8_dpp(lds_addr(T), lds_addr(sInvD + 16 * p), g, inv_last);
+    else panel_last12_dpp(lds_addr(T), lds_addr(sInvD + 16 * p), g, inv_last);
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T[c] = g[c];
+    }
+    return !(inv_last == inv_last);
+}
+
 // Long horizons (one wavefront per SIMD, 512 registers per lane): the accumulator tiles belong in the AGPR half of the
 // register file for all of P2..P5.  Left to itself the allocator parked about half of the 30 tiles of a wavefront in scratch
 // and reloaded them around every trailing update (1.3 GB of scratch writes per 4096-instance launch of the 2x horizon,
@@ -757,6 +806,22 @@ struct WaveLists {
     }
 };
 
+// VS_DIAG_P3 (measurement builds, with the stamps instantiation): where P3's cycles go, seen from wavefront 0 -- panel
+// stream, wait at the barrier behind it, diagonal store + reloads + trailing update, wait at the barrier behind that.
+// Reported by tools/gpu_phases.py in place of the P1 detail rows.
+#ifdef VS_DIAG_P3
+__shared__ unsigned long long vs_diag_p3[4];
+#define VS_P3_MARK(i)                                                                                 \
+    do {                                                                                              \
+        if (DEBUG && W == 0) {                                                                        \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                             \
+            if (lane == 0) vs_diag_p3[i] += now_ - p3_mark;                                           \
+            p3_mark = now_;                                                                           \
+        }                                                                                             \
+    } while (0)
+#else
+#define VS_P3_MARK(i) do { } while (0)
+#endif
 template <class D, int TPW, int W, bool DEBUG, bool PLDS>
 VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sGy, const double* __restrict__ sVprev, int* __restrict__ sFlags,
@@ -810,6 +875,10 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         }
     }
     __syncthreads();
+#ifdef VS_DIAG_P3
+    unsigned long long p3_mark = __builtin_amdgcn_s_memtime();
+    if (DEBUG && W == 0 && lane < 4) vs_diag_p3[lane] = 0;
+#endif
     // (a compile-time loop: the work lists below are indexed with p in constant expressions)
     static_for<0, D::NT>([&](auto pcst) __attribute__((always_inline)) {
         constexpr int p = decltype(pcst)::value;
@@ -817,9 +886,10 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         // rows under the diagonal tile and the wavefronts that share the panel (see panel_factor): one-slot streams of 48
         // rows wherever NWAVES - 1 wavefronts cover the panel, PANEL_SLOTS-slot streams for the tall panels of long horizons
         const int below = D::NP - 16 * p - 16;
-        const bool one_slot = (below + 47) / 48 <= D::NWAVES - 1;
-        const int rpw = one_slot ? 48 : 64 * D::PANEL_SLOTS - 16;
+        const bool one_slot = VS_PANEL_DPP || (below + 47) / 48 <= D::NWAVES - 1;
+        const int rpw = VS_PANEL_DPP ? 64 : one_slot ? 48 : 64 * D::PANEL_SLOTS - 16;
         const int nshare = below <= rpw ? 1 : (below + rpw - 1) / rpw;
+        static_assert((D::NP - 16 + 63) / 64 <= D::NWAVES - 1, "panel 0 leaves one wavefront for the side work");
         double diag[16];  // factored diagonal tile of a shared panel (wavefront 0, lanes 0..15), stored after the barrier
         // broadcast strip of this wavefront (64 doubles): the slot of X_p, which nobody writes before panel p + 1; the last
         // panels (one wavefront each) borrow the not-yet-used z vector
@@ -828,10 +898,15 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
             if (p == D::NT - 1) {
-                if (W == 0 && panel_factor<D, 1, NPIV_LAST, false, PLDS>(sM, sInvD, p, lane, 0, diag, sCol) && lane == 0) sFlags[0] = 1;
+                if constexpr (VS_PANEL_DPP) {
+                    if (W == 0 && panel_last_dpp<D, NPIV_LAST>(sM, sInvD, lane) && lane == 0) sFlags[0] = 1;
+                } else {
+                    if (W == 0 && panel_factor<D, 1, NPIV_LAST, false, PLDS>(sM, sInvD, p, lane, 0, diag, sCol) && lane == 0) sFlags[0] = 1;
+                }
             } else if (W < nshare) {
                 int bad;
-                if (one_slot) bad = panel_factor<D, 1, 16, true, PLDS>(sM, sInvD, p, lane, W, diag, sCol);
+                if constexpr (VS_PANEL_DPP) bad = panel_dpp<D>(sM, sInvD, p, lane, W, diag, sCol);
+                else if (one_slot) bad = panel_factor<D, 1, 16, true, PLDS>(sM, sInvD, p, lane, W, diag, sCol);
                 else bad = panel_factor<D, D::PANEL_SLOTS, 16, true, PLDS>(sM, sInvD, p, lane, W, diag, sCol);
                 if (W == 0 && bad && lane == 0) sFlags[0] = 1;
             }
@@ -847,7 +922,9 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
             if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p - 1 == D::PVT + 1)
                 tile_inverse<D>(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sM + (S::oDual3T0 - S::oM), lane);
         }
+        VS_P3_MARK(0);
         __syncthreads();
+        VS_P3_MARK(1);
         if (W == 0 && p < D::NT - 1 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
             double* Tpp = sM + tile_off_c<D>(p, p) + lane * 17;
 #pragma unroll
@@ -906,7 +983,9 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                     }
                 }
             });
+            VS_P3_MARK(2);
             __syncthreads();
+            VS_P3_MARK(3);
         }
     });
 }
@@ -2018,7 +2097,9 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     const int j = lane & 15, g = lane >> 4;
     // per lane and tile-row pattern (16 t mod 6 = 0, 4, 2 for t mod 3 = 0, 1, 2): the unknown and the block within the tile
     // row of row / column j, and the six entries L[a6][unknown]
-    double Lq[3][NJC];
+    // LqM: the same entries masked to the k block of this lane ([blk(t, j) == blk0(t) + g]: the A operand of a joint x joint
+    // tile, the B operand of a throttle x joint tile), formed once instead of with six selects per tile
+    double Lq[3][NJC], LqM[3][NJC];
     int bin[3];
 #pragma unroll
     for (int pat = 0; pat < 3; ++pat) {
@@ -2026,11 +2107,14 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         bin[pat] = o / NJC;
         const int un = o - NJC * bin[pat];
 #pragma unroll
-        for (int a6 = 0; a6 < NJC; ++a6) Lq[pat][a6] = sBj[((a6 < 3 ? 3 : 6) + a6) * NJ + un];
+        for (int a6 = 0; a6 < NJC; ++a6) {
+            Lq[pat][a6] = sBj[((a6 < 3 ? 3 : 6) + a6) * NJ + un];
+            LqM[pat][a6] = bin[pat] == g ? Lq[pat][a6] : 0.0;
+        }
     }
     // tiles in groups of G (the raw operands of a group are all requested before its arithmetic starts)
     // 18 G + 12 G operand registers (doubles) beside the 18 of Lq; long horizons keep finished tiles in registers meanwhile
-    constexpr int G = D::STRUCT_LONG ? 2 : 3;
+    constexpr int G = 3;
     constexpr int NGRP = (TPW + G - 1) / G;
     static_for<0, NGRP>([&](auto gcst) __attribute__((always_inline)) {
     constexpr int q0 = decltype(gcst)::value * G;
@@ -2080,24 +2164,25 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
         for (int ks = 0; ks < NJC; ++ks) { opa[q - q0][ks] = 0.0; opb[q - q0][ks] = 0.0; }
         if constexpr (t < D::NTRI) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
+            // rows / columns of the dummy unknowns exist in the last joint tile row / column only (compile time)
+            constexpr bool DUMMY_ROWS = 16 * ti + 16 > D::NUY, DUMMY_COLS = 16 * tj + 16 > D::NUY;
             if constexpr (ti < PVT) {
-                const bool okm = 16 * ti + j < D::NUY && bin[ti % 3] == g;   // A: row j of tile row ti sits in k block g
-                const bool okn = 16 * tj + j < D::NUY;
+                const bool okm = 16 * ti + j < D::NUY, okn = 16 * tj + j < D::NUY;
 #pragma unroll
                 for (int ks = 0; ks < NJC; ++ks) {
                     const int h3 = 3 * (ks / 3);
                     const double hl = fma(raw[q - q0][ks][2], Lq[tj % 3][h3 + 2],
                                           fma(raw[q - q0][ks][1], Lq[tj % 3][h3 + 1], raw[q - q0][ks][0] * Lq[tj % 3][h3]));
-                    opa[q - q0][ks] = okm ? Lq[ti % 3][ks] : 0.0;
-                    opb[q - q0][ks] = okn ? hl : 0.0;
+                    opa[q - q0][ks] = (!DUMMY_ROWS || okm) ? LqM[ti % 3][ks] : 0.0;   // A: row j of tile row ti sits in k block g
+                    opb[q - q0][ks] = (!DUMMY_COLS || okn) ? hl : 0.0;
                 }
             } else if constexpr (tj < PVT) {
                 const bool okr = 16 * (ti - PVT) + j <= NV;
-                const bool okn = 16 * tj + j < D::NUY && bin[tj % 3] == g;
+                const bool okn = 16 * tj + j < D::NUY;
 #pragma unroll
                 for (int ks = 0; ks < NJC; ++ks) {
                     opa[q - q0][ks] = okr ? raw[q - q0][ks][0] : 0.0;
-                    opb[q - q0][ks] = okn ? Lq[tj % 3][ks] : 0.0;
+                    opb[q - q0][ks] = (!DUMMY_COLS || okn) ? LqM[tj % 3][ks] : 0.0;
                 }
             }
         }
@@ -2246,6 +2331,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     } while (0)
     using S = Smem<D>;
     constexpr bool FUSED_DISPATCH = FORM == 1 && !STAMPS;   // entries + P2 + P3 behind one wave dispatch (see P1)
+    // steps of the joint reduction that run in P0 (wavefront 3); the rest follows a generator chain in P1.  Long horizons
+    // have ~9 k cycles of slack behind the generator chains, short ones ~3 k.
+    constexpr int QR_P0_STEPS = D::STRUCT_LONG ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* sIn = smem + S::oIn;
     double* sA = smem + S::oA;
@@ -2319,7 +2407,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     // lengthen P0).  The structured form needs it for the tile entries only: three steps here (hidden), the other three in a
     // generator wavefront after its chain, in the ~3 k cycles it would otherwise wait for the throttle wavefronts (below).
     if (wave == 3) {
-        if constexpr (FORM == 1) p0_joint_reduction<D, 0, 3>(smem, lane);
+        if constexpr (FORM == 1) p0_joint_reduction<D, 0, QR_P0_STEPS>(smem, lane);
         else p0_joint_reduction<D>(smem, lane);
     }
 
@@ -2391,7 +2479,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         VS_TIC();
         if (wave < 2) {
             p1s_chain<D, 0>(cfg, wave, lane, smem);
-            if (wave == 0) p0_joint_reduction<D, 3, NJC>(smem, lane);   // (second half; writes Bj and sQR, which nobody touches
+            if (wave == 0) p0_joint_reduction<D, QR_P0_STEPS, NJC>(smem, lane);   // (second half; writes Bj and sQR, which nobody touches
                                                                         // before the barrier below)
         } else {
             p1s_chain<D, 1>(cfg, wave - 2, lane, smem);
@@ -2898,6 +2986,13 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(7);
     VS_REFRESH_IDS();
     // ---------------------------------------------------------------- P6 forward simulation + outputs
+    // the output pointers: requested from the kernarg segment here, a phase ahead of their use (a scalar load is a
+    // ~0.5 us round trip when it misses, and nothing else in P6 wants the scalar registers)
+    const SolveArgs* ka = late_args();
+    double* xout = ka->xout;
+    double* fmout = ka->fmout;
+    int* status_out = ka->status_out;
+    int* iters_out = ka->iters_out;
     // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c  (Bj U = R^T y in the reduced unknowns)
     for (int e = tid; e < NX * D::N; e += D::BLOCK) {
         const int k = e / NX, r = e - k * NX;
@@ -3051,11 +3146,6 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(8);
     VS_REFRESH_IDS();
 
-    const SolveArgs* ka = late_args();
-    double* xout = ka->xout;
-    double* fmout = ka->fmout;
-    int* status_out = ka->status_out;
-    int* iters_out = ka->iters_out;
     if (xout != nullptr) {
         double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
         for (int i = tid; i < D::NXS / 2; i += D::BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
@@ -3085,6 +3175,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     if constexpr (STAMPS) {
         unsigned long long* st_ = late_args()->stamps;
         if (threadIdx.x == 0 && st_ != nullptr) {
+#ifdef VS_DIAG_P3
+            for (int i = 0; i < 4; ++i) t_acc[i] = vs_diag_p3[i];
+#endif
             t_acc[5] = __builtin_amdgcn_s_memrealtime() - rt0;
             t_acc[4] = rt0;  // absolute start (global 100 MHz counter): start skew across the workgroups of a launch
             for (int i = 0; i < 6; ++i) st_[size_t(blockIdx.x) * 16 + 10 + i] = t_acc[i];
@@ -3260,7 +3353,8 @@ hipError_t launch_solve_dims(int form, const DevCfg& cfg, const double* d_in, in
     if constexpr (D::STRUCT_P1) {
         if (form != 2) {
             // two workgroups per CU once the batch exceeds the CUs: the panel streams with LDS broadcasts (see panel_factor)
-            if constexpr (D::WG_PER_CU == 2 && !STAMPS) {
+            // (only the C++ streams have that form; the DPP streams broadcast inside the FMA)
+            if constexpr (D::WG_PER_CU == 2 && !STAMPS && !VS_PANEL_DPP) {
                 static std::atomic<int> cus[MAX_DEVICES];
                 int ncu = cus[dev].load(std::memory_order_relaxed);
                 if (ncu == 0) {

@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Generates csrc/vsmpc_panel_asm.inc: the 16-pivot panel streams of P3 as hand-scheduled blocks of gfx950 assembly.
+
+Why.  A panel stream is ~550 vector instructions in ONE wavefront, and a lone wavefront issues one FP64 vector instruction
+every ~5.5 cycles whatever the dependencies look like (tools/microbench/lat_probe.hip, f64_issue.hip): the stream costs
+its instruction count.  In the C++ form (panel_factor<1, 16> of vsmpc_kernels.hip) two thirds of the instructions are
+v_readlane pairs: every entry l_cj of the pivot column is moved to a scalar register pair so that the FMA that updates
+column c can read it.  gfx90a+ has a cheaper broadcast for FP64: DPP `row_newbcast:c` on v_fmac_f64 -- lane c of every row
+of 16 lanes feeds all 16 lanes of that row, inside the FMA.  That needs the broadcast source in every 16-lane row, so:
+
+Layout ("dpp" stream).  Lane L = 16 r + c carries
+    a[0..15]   panel row L of the 64 rows below the diagonal tile this wavefront owns     (its own LDS row)
+    g[0..15]   row c of the DIAGONAL tile                                                (the same in all four lane rows)
+The diagonal tile is factored redundantly in g (four copies, bit-identical), and per pivot j and column c > j
+    g[c] += (-l_cj) * g_j       a[c] += (-l_cj) * a_j        with l_cj = lane c of the scaled pivot column g_j, by DPP.
+Two instructions per column instead of three, no scalar round trips, and 64 panel rows per stream instead of 48 (the C++
+SPLIT form keeps the diagonal tile in lanes 0..15).  448 instructions + 48 LDS accesses against 568 + 32.
+The product (-l_cj) * l_j and the accumulation order are those of the C++ form: results are bit-identical.
+
+Also generated: the "readlane" stream (the C++ algorithm, only re-ordered), kept for the microbenchmark's comparison.
+
+Scheduling.  Dependencies (RAW / WAR / WAW) are derived from each instruction's register reads and writes in program order;
+a list scheduler with a small in-order issue model (issue cost and result latency per class) orders them, longest remaining
+path first; a last pass pads the wait states gfx940 does NOT interlock (LLVM's GCNHazardRecognizer does not see inside
+inline assembly): VALU write -> DPP read of that VGPR 2, transcendental result -> VALU use 1, VALU write -> v_readlane
+read 1, VALU-written SGPR -> VALU read 2.
+The tile lives in fixed physical registers because inline-assembly operands cannot name the halves of a 64-bit register;
+the output operands are bound to exactly those registers ("={v[100:101]}"), so no copies are made.
+
+    python tools/gen_panel_asm.py            # rewrites the .inc (committed; build.py does not run this)
+"""
+from __future__ import annotations
+
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd", "csrc", "vsmpc_panel_asm.inc")
+
+NP = 16
+# (issue cycles, cycles until the result can be consumed without a stall) per class: lone wavefront
+COST = {"fma": (6, 10), "mul": (6, 10), "min": (6, 10), "dpp": (6, 12), "movdpp": (6, 12), "rl": (5, 34), "rsq": (10, 28),
+        "cmp": (4, 8), "cnd": (4, 6), "mov": (4, 6), "smov": (2, 4), "dsr": (5, 70), "dsw": (5, 5), "wait": (2, 2)}
+
+
+def vp(base):
+    return f"v[{base}:{base + 1}]"
+
+
+def sp(base):
+    return f"s[{base}:{base + 1}]"
+
+
+def regs(prefix, base, n=2):
+    return [f"{prefix}{base + i}" for i in range(n)]
+
+
+class Node:
+    def __init__(self, kind, text, rd, wr, dpp_src=()):
+        self.kind, self.text, self.rd, self.wr, self.dpp_src = kind, text, list(rd), list(wr), list(dpp_src)
+        self.deps, self.succ, self.prio, self.done_at = set(), [], 0, 0
+
+
+class Stream:
+    def __init__(self):
+        self.nodes = []
+
+    def add(self, kind, text, rd, wr, dpp_src=()):
+        self.nodes.append(Node(kind, text, rd, wr, dpp_src))
+
+    def link(self):
+        last_w, readers = {}, {}
+        for n in self.nodes:
+            for r in n.rd:
+                if r in last_w:
+                    n.deps.add(last_w[r])                    # RAW
+            for w in n.wr:
+                for q in readers.get(w, []):
+                    n.deps.add(q)                             # WAR
+                if w in last_w:
+                    n.deps.add(last_w[w])                     # WAW
+            for r in n.rd:
+                readers.setdefault(r, []).append(n)
+            for w in n.wr:
+                last_w[w] = n
+                readers[w] = []
+        for n in self.nodes:
+            n.deps.discard(n)
+            for d in n.deps:
+                d.succ.append(n)
+
+    def schedule(self):
+        self.link()
+        for n in reversed(self.nodes):
+            n.prio = COST[n.kind][1] + max((s.prio for s in n.succ), default=0)
+        pending = {id(n): len(n.deps) for n in self.nodes}
+        ready_at = {id(n): 0 for n in self.nodes}
+        avail = [n for n in self.nodes if not n.deps]
+        order, time = [], 0
+        while avail:
+            ok = [n for n in avail if ready_at[id(n)] <= time]
+            pick = max(ok, key=lambda n: n.prio) if ok else min(avail, key=lambda n: (ready_at[id(n)], -n.prio))
+            time = max(time, ready_at[id(pick)])
+            avail.remove(pick)
+            order.append(pick)
+            issue, lat = COST[pick.kind]
+            pick.done_at = time + lat
+            time += issue
+            for s in pick.succ:
+                pending[id(s)] -= 1
+                # RAW wants the result, WAR / WAW only the issue order: the latency counts for true dependencies only
+                ready_at[id(s)] = max(ready_at[id(s)], pick.done_at if set(pick.wr) & set(s.rd) else 0)
+                if pending[id(s)] == 0:
+                    avail.append(s)
+        assert len(order) == len(self.nodes)
+        return order, time
+
+    def emit(self):
+        order, cycles = self.schedule()
+        lines, writer, nops = [], {}, 0   # writer: register -> (index in `lines` of the instruction that wrote it, its kind)
+        for n in order:
+            need = 0
+            for r in n.rd:
+                if r not in writer:
+                    continue
+                at, kind = writer[r]
+                gap = len(lines) - at - 1                     # instructions already between the two
+                valu_w = kind not in ("dsr", "smov", "wait")
+                want = 0
+                if r in n.dpp_src and valu_w:
+                    want = 2
+                if kind == "rsq":
+                    want = max(want, 1)
+                if n.kind == "rl" and r.startswith("v") and valu_w:
+                    want = max(want, 1)
+                if kind == "rl" and r.startswith("s"):
+                    want = max(want, 2)
+                need = max(need, want - gap)
+            if need > 0:
+                lines.append(f"s_nop {need - 1}")
+                nops += need
+            lines.append(n.text)
+            for w in n.wr:
+                writer[w] = (len(lines) - 1, n.kind)
+        return lines, cycles, len(order), nops
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# register maps
+A0, G0 = 100, 132                                             # a[c] = v[A0 + 2c : +1], g[c] = v[G0 + 2c : +1]
+Y, T, E, Z, W, INV, DP = 164, 166, 168, 170, 172, 174, 176
+LDA, STA, DGA, IVA = 178, 179, 180, 181                       # LDS byte addresses: row load, row store, diagonal row, 1 / L_jj
+K375 = 76
+LAST_PANEL_PIVOTS = [8, 12]                                   # NZ - 16 (NT - 1) of the built horizons (vsmpc_device.hpp)
+
+
+def a(c):
+    return A0 + 2 * c
+
+
+def g(c):
+    return G0 + 2 * c
+
+
+def prologue(s, with_a):
+    if with_a:
+        for c in range(NP):
+            s.add("dsr", f"ds_read_b64 {vp(a(c))}, v{LDA} offset:{8 * c}", [f"v{LDA}"], regs("v", a(c)) + ["lgkm"])
+    for c in range(NP):
+        s.add("dsr", f"ds_read_b64 {vp(g(c))}, v{DGA} offset:{8 * c}", [f"v{DGA}"], regs("v", g(c)) + ["lgkm"])
+    s.add("smov", f"s_mov_b32 s{K375}, 0", [], [f"s{K375}"])
+    s.add("smov", f"s_mov_b32 s{K375 + 1}, 0x3fd80000", [], [f"s{K375 + 1}"])
+    # one wait for all loads (finer counts would let pivot 0 start earlier: ~100 cycles, not worth the bookkeeping)
+    allr = [r for c in range(NP) for r in regs("v", g(c))] + ([r for c in range(NP) for r in regs("v", a(c))] if with_a else [])
+    s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm"], allr)
+
+
+def epilogue(s):
+    # the compiler's wait-count bookkeeping does not see the stores issued in here: they are complete when the block ends
+    s.add("wait", "s_waitcnt lgkmcnt(0)", ["lds"], ["lds"])
+
+
+def rsqrt_chain(s, d_src, d_regs):
+    """fast_rsqrt of vsmpc_kernels.hip on the pivot in `d_src` -> INV"""
+    s.add("rsq", f"v_rsq_f64_e32 {vp(Y)}, {d_src}", d_regs, regs("v", Y))
+    s.add("mul", f"v_mul_f64 {vp(T)}, {d_src}, {vp(Y)}", d_regs + regs("v", Y), regs("v", T))
+    s.add("fma", f"v_fma_f64 {vp(E)}, -{vp(T)}, {vp(Y)}, 1.0", regs("v", T) + regs("v", Y), regs("v", E))
+    s.add("mul", f"v_mul_f64 {vp(Z)}, {vp(Y)}, {vp(E)}", regs("v", Y) + regs("v", E), regs("v", Z))
+    s.add("fma", f"v_fma_f64 {vp(W)}, {sp(K375)}, {vp(E)}, 0.5", regs("s", K375) + regs("v", E), regs("v", W))
+    s.add("fma", f"v_fma_f64 {vp(INV)}, {vp(Z)}, {vp(W)}, {vp(Y)}", regs("v", Z) + regs("v", W) + regs("v", Y), regs("v", INV))
+
+
+def stream_dpp(npiv=NP, with_a=True):
+    """with_a = False: the diagonal tile alone (the last panel: npiv pivots, its other rows carried as ordinary rows)"""
+    s = Stream()
+    prologue(s, with_a)
+    for j in range(npiv):
+        s.add("movdpp", f"v_mov_b64_dpp {vp(DP)}, {vp(g(j))} row_newbcast:{j} row_mask:0xf bank_mask:0xf", regs("v", g(j)), regs("v", DP),
+              dpp_src=regs("v", g(j)))
+        rsqrt_chain(s, vp(DP), regs("v", DP))
+        # 1 / L_jj for P5 and the tile inverses: the same value from every lane to the same address (wavefront 0; the others
+        # are handed a dummy).  A non-positive pivot needs no bookkeeping: its reciprocal square root is NaN and so is
+        # everything computed from it, down to the last pivot's, which the caller tests.
+        s.add("dsw", f"ds_write_b64 v{IVA}, {vp(INV)} offset:{8 * j}", [f"v{IVA}"] + regs("v", INV), ["lds"])
+        s.add("mul", f"v_mul_f64 {vp(g(j))}, {vp(g(j))}, {vp(INV)}", regs("v", g(j)) + regs("v", INV), regs("v", g(j)))
+        if with_a:
+            s.add("mul", f"v_mul_f64 {vp(a(j))}, {vp(a(j))}, {vp(INV)}", regs("v", a(j)) + regs("v", INV), regs("v", a(j)))
+            s.add("dsw", f"ds_write_b64 v{STA}, {vp(a(j))} offset:{8 * j}", [f"v{STA}"] + regs("v", a(j)), ["lds"])
+        for c in range(j + 1, NP):
+            for dst, src1 in ((g(c), g(j)), (a(c), a(j))) if with_a else ((g(c), g(j)),):
+                s.add("dpp", f"v_fmac_f64_dpp {vp(dst)}, -{vp(g(j))}, {vp(src1)} row_newbcast:{c} row_mask:0xf bank_mask:0xf",
+                      regs("v", g(j)) + regs("v", src1) + regs("v", dst), regs("v", dst), dpp_src=regs("v", g(j)))
+    epilogue(s)
+    return s
+
+
+HEADER = """// GENERATED by tools/gen_panel_asm.py -- do not edit (the why and the how are in that file's header).
+// Sixteen-pivot panel streams of P3 as hand-scheduled gfx950 assembly.  Same arithmetic, operation by operation, as
+// panel_factor<1, 16> (bit-identical results); what differs is how the pivot column reaches the other lanes and the order.
+"""
+
+
+def function(name, s, comment, with_a):
+    lines, cycles, ninstr, nops = s.emit()
+    body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
+    outs = [f'"={{v[{g(c)}:{g(c) + 1}]}}"(g[{c}])' for c in range(NP)] + [f'"={{v[{INV}:{INV + 1}]}}"(inv_last)']
+    ins = [f'"{{v{DGA}}}"(diag_addr)', f'"{{v{IVA}}}"(invd_addr)'] + ([f'"{{v{LDA}}}"(load_addr)', f'"{{v{STA}}}"(store_addr)'] if with_a else [])
+    bound = set(regs("v", INV) + [f"v{DGA}", f"v{IVA}"] + ([f"v{LDA}", f"v{STA}"] if with_a else []))
+    for c in range(NP):
+        bound.update(regs("v", g(c)))
+    touched = set()
+    for n in s.nodes:
+        touched.update(r for r in n.rd + n.wr if r[0] in "vs" and r[1:].isdigit())
+    clob = sorted(touched - bound, key=lambda r: (r[0], int(r[1:])))
+    clobbers = ", ".join(f'"{r}"' for r in clob) + ', "memory"'
+    sig = ("unsigned load_addr, unsigned store_addr, " if with_a else "") + "unsigned diag_addr, unsigned invd_addr, double (&g)[16], double& inv_last"
+    text = f"\n// {comment}\n// {ninstr} instructions + {nops} wait states, {cycles} cycles in the generator's issue model.\n"
+    text += f"VS_DEV void {name}({sig}) {{\n    asm volatile(\n{body}\n"
+    text += "        : " + ", ".join(outs) + "\n        : " + ", ".join(ins) + "\n        : " + clobbers + ");\n}\n"
+    return text, ninstr, nops, cycles
+
+
+def main():
+    import sys
+    last = [int(x) for x in sys.argv[1:]] or LAST_PANEL_PIVOTS
+    text = HEADER
+    todo = [("panel16_dpp", stream_dpp(), "Lane 16 r + c carries the panel row at `load_addr` (stored, finished, to `store_addr`: the same row, or a 16-double\n"
+             "// dummy for rows beyond the matrix) and row c of the diagonal tile (`diag_addr`, returned factored in g).  1 / L_jj goes to\n"
+             "// invd_addr[j] (every lane writes it: a dummy for all wavefronts but one); inv_last = 1 / L_15,15 is NaN iff a pivot was\n"
+             "// not positive.", True)]
+    for npiv in last:
+        todo.append((f"panel_last{npiv}_dpp", stream_dpp(npiv, False), f"The last panel: {npiv} pivots in the diagonal tile, whose other rows are carried as ordinary "
+                     f"rows.\n// Lane 16 r + c carries row c (r = 0 is the copy that is stored); inv_last = 1 / L_{npiv - 1},{npiv - 1}.", False))
+    for name, s, comment, with_a in todo:
+        t, ninstr, nops, cycles = function(name, s, comment, with_a)
+        text += t
+        print(f"{name}: {ninstr} instructions, {nops} wait states, modelled {cycles} cycles")
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("->", OUT)
+
+
+if __name__ == "__main__":
+    main()
