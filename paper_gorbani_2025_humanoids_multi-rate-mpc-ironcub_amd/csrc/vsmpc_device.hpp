@@ -202,13 +202,48 @@ VS_HD constexpr int wrow(int r) { return r < 12 ? r : r + 8; }  // weighted-row 
 // the tile of C = sum_k Y_k^T Y_k becomes non-zero), SORTED by that stage and padded to a multiple of 4
 // with never-active dummies.  Entry s is owned by wavefront s % NWAVES, slot s / NWAVES, so at every stage the
 // active slots of a wavefront form a prefix and the four wavefronts carry the same number of them (+-1).
-template <class D>
+//
+// PIPE (kernel v27, the structured form's pipelined P3): wavefront 0 is the PANEL wavefront -- it owns no tile; its
+// slots list the tiles of tile column 0, whose entries it forms and hands to LDS as the first panel -- and ALL tiles are
+// dealt to wavefronts 1..3 in column-major order (the tiles of a column, and therefore the updates of every panel step,
+// spread evenly over the three).  A wavefront >= 1 never forms the entries of a column-0 tile: they reach its registers
+// factored, when panel 0 is done.  Same indexing (entry q * NWAVES + W), TPW = max(ceil(NTRI / 3), NT) slots.
+template <class D, bool PIPE = false>
 struct TileTab {
-    static constexpr int NPAD = ((D::NTRI + D::NWAVES - 1) / D::NWAVES) * D::NWAVES;
+    static constexpr int NOWN = PIPE ? D::NWAVES - 1 : D::NWAVES;
+    static constexpr int TPW = PIPE ? ((D::NTRI + NOWN - 1) / NOWN > D::NT ? (D::NTRI + NOWN - 1) / NOWN : D::NT)
+                                    : (D::NTRI + D::NWAVES - 1) / D::NWAVES;
+    static constexpr int NPAD = TPW * D::NWAVES;
+    static constexpr int NEVER = 1 << 20;
     int ti[NPAD];
     int tj[NPAD];
     int ts[NPAD];
-    constexpr TileTab() : ti{}, tj{}, ts{} {
+    bool valid[NPAD];
+    constexpr bool ok(int t) const { return valid[t]; }
+    // does wavefront w form the entries of its slot t (P1 / P2)?
+    constexpr bool forms(int t, int w) const { return ok(t) && !(PIPE && w > 0 && tj[t] == 0); }
+    // does wavefront w hold tile t from P3 on (updates, the finished factor, P5)?
+    constexpr bool holds(int t, int w) const { return ok(t) && !(PIPE && w == 0); }
+    constexpr TileTab() : ti{}, tj{}, ts{}, valid{} {
+        for (int t = 0; t < NPAD; ++t) { ti[t] = 0; tj[t] = 0; ts[t] = NEVER; valid[t] = !PIPE && t < D::NTRI; }
+        if (PIPE) {
+            for (int i = 0; i < D::NT; ++i) {
+                ti[i * D::NWAVES] = i;
+                ts[i * D::NWAVES] = tile_first_stage<D>(i);
+                valid[i * D::NWAVES] = true;
+            }
+            int k = 0;
+            for (int j = 0; j < D::NT; ++j)
+                for (int i = j; i < D::NT; ++i, ++k) {
+                    const int t = (k / NOWN) * D::NWAVES + 1 + k % NOWN;
+                    ti[t] = i;
+                    tj[t] = j;
+                    const int a = tile_first_stage<D>(i), b = tile_first_stage<D>(j);
+                    ts[t] = a > b ? a : b;
+                    valid[t] = true;
+                }
+            return;
+        }
         int t = 0;
         for (int i = 0; i < D::NT; ++i)
             for (int j = 0; j <= i; ++j, ++t) {
@@ -217,7 +252,6 @@ struct TileTab {
                 const int a = tile_first_stage<D>(i), b = tile_first_stage<D>(j);
                 ts[t] = a > b ? a : b;
             }
-        for (; t < NPAD; ++t) { ti[t] = 0; tj[t] = 0; ts[t] = 1 << 20; }
         for (int a = 1; a < D::NTRI; ++a) {  // stable insertion sort by first stage
             const int ki = ti[a], kj = tj[a], ks = ts[a];
             int b = a - 1;

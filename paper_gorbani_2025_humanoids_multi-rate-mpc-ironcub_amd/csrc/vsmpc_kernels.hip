@@ -49,8 +49,8 @@ namespace vsmpc {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 
-template <class D>
-__device__ constexpr TileTab<D> kTileTab{};
+template <class D, bool PIPE = false>
+__device__ constexpr TileTab<D, PIPE> kTileTab{};
 template <class D>
 __device__ constexpr NactTab<D> kNactTab{};
 template <class D>
@@ -681,20 +681,29 @@ VS_DEV int panel_factor(double* __restrict__ Lb, double* __restrict__ sInvD, int
 #include "vsmpc_panel_asm.inc"
 VS_DEV unsigned lds_addr(const double* q) { return unsigned(reinterpret_cast<uintptr_t>(q)); }   // flat -> LDS byte address
 
-// Shared panel p < NT - 1: rows 16 p + 16 + 64 w .. of the panel column; the factored diagonal tile comes back in `diag`
-// (lanes 0..15; stored by wavefront 0 after the barrier, the others read the unfactored tile meanwhile) and 1 / L_jj goes
-// to sInvD from wavefront 0.  `scratch` = 32 doubles of this wavefront nobody reads: rows beyond the matrix and the other
-// wavefronts' 1 / L_jj end there.  Returns non-zero if a pivot was not positive (its reciprocal square root is NaN, and
-// then so is everything after it down to the last one).
-template <class D>
+// Panel p < NT - 1, wavefront w of those that share it, S row slots per lane: rows 16 p + 16 + 64 (S w + s) + lane of the
+// panel column; the factored diagonal tile comes back in `diag` (lanes 0..15) and 1 / L_jj goes to sInvD from wavefront 0.
+// `scratch` = 32 doubles of this wavefront nobody reads: rows beyond the matrix and the other wavefronts' 1 / L_jj end there.
+// Returns non-zero if a pivot was not positive (its reciprocal square root is NaN, and then so is everything after it down
+// to the last one).
+template <class D, int S = 1>
 VS_DEV int panel_dpp(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16],
                       double* scratch) {
-    const int r = 16 * p + 16 + 64 * w + lane;
-    const bool ok = r < D::NP;
-    const unsigned ld = lds_addr(Lb + tile_off<D>(ok ? (r >> 4) : p, p) + (r & 15) * 17);
+    unsigned ld[S], st[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int r = 16 * p + 16 + 64 * (S * w + s) + lane;
+        const bool ok = r < D::NP;
+        ld[s] = lds_addr(Lb + tile_off<D>(ok ? (r >> 4) : p, p) + (r & 15) * 17);
+        st[s] = ok ? ld[s] : lds_addr(scratch);
+    }
+    const unsigned dg = lds_addr(Lb + tile_off<D>(p, p) + (lane & 15) * 17);
+    const unsigned iv = lds_addr(w == 0 ? sInvD + 16 * p : scratch + 16);
     double inv_last;
-    panel16_dpp(ld, ok ? ld : lds_addr(scratch), lds_addr(Lb + tile_off<D>(p, p) + (lane & 15) * 17),
-                lds_addr(w == 0 ? sInvD + 16 * p : scratch + 16), diag, inv_last);
+    static_assert(S >= 1 && S <= 3, "tools/gen_panel_asm.py generates one, two and three row slots");
+    if constexpr (S == 1) panel16x1_dpp(ld[0], st[0], dg, iv, diag, inv_last);
+    else if constexpr (S == 2) panel16x2_dpp(ld[0], st[0], ld[1], st[1], dg, iv, diag, inv_last);
+    else panel16x3_dpp(ld[0], st[0], ld[1], st[1], ld[2], st[2], dg, iv, diag, inv_last);
     return !(inv_last == inv_last);
 }
 // The last panel (one wavefront): NPIV pivots, the remaining rows of the tile (gradient row, padding) are ordinary rows.
@@ -788,19 +797,28 @@ VS_DEV void tile_inverse_rows(const double* __restrict__ Lpp, const double* __re
 // Compile-time work lists of wavefront W: for every panel p the slots whose tile lies right of the panel column
 // (trailing update), and for every tile row r the slots whose tile (r, q), q < min(r, PVT), is kept in registers
 // after P3 (back-substitution).
-template <class D, int TPW, int W>
+template <class D, int TPW, int W, bool PIPE = false>
 struct WaveLists {
     int ntrail[D::NT];
     int trail[D::NT][TPW];
     int nrow[D::NT];
     int row[D::NT][TPW];
-    constexpr WaveLists() : ntrail{}, trail{}, nrow{}, row{} {
-        constexpr TileTab<D> tab{};
+    // PIPE: the update of panel p in two parts -- the tiles of column p + 1 (the next panel: `first`, on the critical path)
+    // and everything right of it (`rest`, under the next panel's stream)
+    int nfirst[D::NT];
+    int first[D::NT][TPW];
+    int nrest[D::NT];
+    int rest[D::NT][TPW];
+    constexpr WaveLists() : ntrail{}, trail{}, nrow{}, row{}, nfirst{}, first{}, nrest{}, rest{} {
+        constexpr TileTab<D, PIPE> tab{};
         for (int p = 0; p < D::NT; ++p) {
             for (int q = 0; q < TPW; ++q) {
                 const int t = q * D::NWAVES + W;
-                if (t < D::NTRI && tab.tj[t] > p) trail[p][ntrail[p]++] = q;
-                if (t < D::NTRI && tab.ti[t] == p && tab.tj[t] < p && tab.tj[t] < D::PVT) row[p][nrow[p]++] = q;
+                if (!tab.holds(t, W)) continue;
+                if (tab.tj[t] > p) trail[p][ntrail[p]++] = q;
+                if (tab.tj[t] == p + 1) first[p][nfirst[p]++] = q;
+                if (tab.tj[t] > p + 1) rest[p][nrest[p]++] = q;
+                if (tab.ti[t] == p && tab.tj[t] < p && tab.tj[t] < D::PVT) row[p][nrow[p]++] = q;
             }
         }
     }
@@ -822,13 +840,90 @@ __shared__ unsigned long long vs_diag_p3[4];
 #else
 #define VS_P3_MARK(i) do { } while (0)
 #endif
-template <class D, int TPW, int W, bool DEBUG, bool PLDS>
+// PIPE: acc[q] -= L_ip L_jp^T for the slots of one work list of wavefront W (KIND 1: the tiles of column PP + 1, which are
+// then handed to LDS as the next panel; KIND 2: everything right of it), panel column PP in LDS.  Two tiles at a time:
+// independent v_mfma_f64_16x16x4_f64 issue every 64 cycles, a dependent one every ~95 -- since the pipelined schedule put
+// these chains on the critical path (first) or beside a panel stream that is no longer than they are (rest), that matters.
+// The operands of the next pair are requested before the chains of the current one.
+template <class D, int TPW, int W, int PP, int KIND>
+constexpr int pipe_count() {
+    constexpr WaveLists<D, TPW, W, true> wl{};
+    return KIND == 1 ? wl.nfirst[PP] : wl.nrest[PP];
+}
+template <class D, int TPW, int W, int PP, int KIND>
+constexpr int pipe_slot(int a) {
+    constexpr WaveLists<D, TPW, W, true> wl{};
+    return KIND == 1 ? wl.first[PP][a] : wl.rest[PP][a];
+}
+template <class D, int TPW, int W, int PP, int KIND>
+VS_DEV void pipe_update(d4 (&acc)[TPW], double* __restrict__ sM, int lrow, int crow) {
+    constexpr TileTab<D, true> tab{};
+    constexpr int n = pipe_count<D, TPW, W, PP, KIND>();
+    double la[2][2][4], lb[2][2][4];   // [buffer][tile of the pair][k-step]
+    auto request = [&](auto acst) __attribute__((always_inline)) {
+        constexpr int a = decltype(acst)::value;   // first tile of the pair
+        static_for<0, 2>([&](auto ucst) __attribute__((always_inline)) {
+            constexpr int u = decltype(ucst)::value;
+            if constexpr (a + u < n) {
+                constexpr int t = pipe_slot<D, TPW, W, PP, KIND>(a + u) * D::NWAVES + W;
+                const double* Lip = sM + tile_off_c<D>(tab.ti[t], PP) + lrow;
+                const double* Ljp = sM + tile_off_c<D>(tab.tj[t], PP) + lrow;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { la[(a >> 1) & 1][u][ks] = -Lip[4 * ks]; lb[(a >> 1) & 1][u][ks] = Ljp[4 * ks]; }
+            }
+        });
+    };
+    request(std::integral_constant<int, 0>{});
+    static_for<0, (TPW + 1) / 2>([&](auto hcst) __attribute__((always_inline)) {
+        constexpr int a = 2 * decltype(hcst)::value;
+        if constexpr (a < n) {
+            request(std::integral_constant<int, a + 2>{});
+            constexpr int q0 = pipe_slot<D, TPW, W, PP, KIND>(a), q1 = pipe_slot<D, TPW, W, PP, KIND>(a + 1 < n ? a + 1 : a);
+            constexpr int b = (a >> 1) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][ks], lb[b][0][ks], acc[q0], 0, 0, 0);
+                if constexpr (a + 1 < n) acc[q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][1][ks], lb[b][1][ks], acc[q1], 0, 0, 0);
+            }
+            if constexpr (KIND == 1) {
+                static_for<0, 2>([&](auto ucst) __attribute__((always_inline)) {
+                    constexpr int u = decltype(ucst)::value;
+                    if constexpr (a + u < n) {
+                        constexpr int q = u ? q1 : q0;
+                        double* T = sM + tile_off_c<D>(tab.ti[q * D::NWAVES + W], PP + 1) + crow;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                    }
+                });
+            }
+        }
+    });
+}
+
+// X = L_pp^-1 by the DPP rows stream on the identity (tools/gen_panel_asm.py, stream_inverse): 234 instructions, ~1.3 k cycles
+// against ~2.5 k for tile_inverse (LDS broadcast + FMA pairs)
+VS_DEV void tile_inverse_dpp(const double* __restrict__ Lpp, const double* __restrict__ invd, double* __restrict__ X, int lane) {
+    panel_inverse_dpp(lds_addr(Lpp + (lane & 15) * 17), lds_addr(invd), lds_addr(X + (lane & 15)), lane & 15);
+}
+
+// Which of the wavefronts 1..3 inverts the diagonal tile of panel p - 1 while panel p is streamed (PIPE): the one with the
+// fewest tiles in the update that runs beside it.
+template <class D, int TPW>
+constexpr int pipe_inverse_wave(int p) {
+    constexpr WaveLists<D, TPW, 1, true> w1{};
+    constexpr WaveLists<D, TPW, 2, true> w2{};
+    constexpr WaveLists<D, TPW, 3, true> w3{};
+    const int n1 = w1.nrest[p - 1], n2 = w2.nrest[p - 1], n3 = w3.nrest[p - 1];
+    return (n3 <= n1 && n3 <= n2) ? 3 : (n2 <= n1 ? 2 : 1);
+}
+
+template <class D, int TPW, int W, bool DEBUG, bool PLDS, bool PIPE = false>
 VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], double* __restrict__ sM, double* __restrict__ sInvD,
                           const double* __restrict__ sGy, const double* __restrict__ sVprev, int* __restrict__ sFlags,
                           double* __restrict__ sXinv, double* __restrict__ sW, double* __restrict__ dbgL, int lane,
                           int crow, int lrow, double* sZ_) {
-    constexpr TileTab<D> tab{};
-    constexpr WaveLists<D, TPW, W> wl{};
+    constexpr TileTab<D, PIPE> tab{};
+    constexpr WaveLists<D, TPW, W, PIPE> wl{};
     using S = Smem<D>;
     constexpr int PVT = D::PVT;
     constexpr int GL = D::NZ & 15;  // local row of the gradient row (row NZ) in the last tile row
@@ -841,7 +936,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
     static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
-        if constexpr (t < D::NTRI) {
+        if constexpr (tab.forms(t, W)) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti == tj && 16 * ti + 16 <= D::NU) {
                 // unit weights on the reduced joint unknowns (U^T W U / 2 = |y|^2 / 2 + |n|^2 / 2, costsVSMPC.cpp:375-381,
@@ -868,7 +963,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int t = q * D::NWAVES + W;
-        if (t < D::NTRI && tab.tj[t] == 0) {
+        if (tab.forms(t, W) && tab.tj[t] == 0) {
             double* T = sM + tile_off_c<D>(tab.ti[t], 0) + crow;
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
@@ -879,6 +974,87 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
     unsigned long long p3_mark = __builtin_amdgcn_s_memtime();
     if (DEBUG && W == 0 && lane < 4) vs_diag_p3[lane] = 0;
 #endif
+    // ---------------------------------------------------------------- PIPE: the pipelined schedule (kernel v27)
+    // Wavefront 0 factors panel p while wavefronts 1..3 -- which hold all the tiles -- apply panel p - 1 to everything right of
+    // column p.  Only the update of column p + 1 itself (`first`: one or two tiles per wavefront) stands between two streams:
+    //     wavefront 0                         wavefronts 1..3
+    //     stream(p)                           rest-update(p - 1): tiles (i, j), j > p, with column p - 1;  one of them: X_(p-1)
+    //     ----------------------------------- barrier: column p factored, the ring slot of column p - 1 free
+    //     store the diagonal tile             column p's finished tiles -> registers; first-update(p): tiles (i, p + 1) with
+    //                                         column p, handed to LDS (ring slot of column p - 1 / the corner)
+    //     ----------------------------------- barrier: column p + 1 complete
+    // Panel 0 has no update beside it: it is shared like in the plain schedule (one 64-row stream per wavefront); from
+    // panel 1 on wavefront 0 carries all rows below the diagonal tile in one to three row slots.
+    if constexpr (PIPE) {
+        static_assert(VS_PANEL_DPP, "the pipelined schedule is built on the DPP panel streams");
+        static_for<0, D::NT>([&](auto pcst) __attribute__((always_inline)) {
+            constexpr int p = decltype(pcst)::value;
+            if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
+            constexpr int below = D::NP - 16 * p - 16;
+            constexpr int nshare0 = (below + 63) / 64;
+            constexpr int SL = below <= 64 ? 1 : (below <= 128 ? 2 : 3);
+            static_assert(p == 0 ? nshare0 <= D::NWAVES - 1 : below <= 192, "rows of a panel fit the streams");
+            double* scratch = p <= PVT ? sXinv + p * D::TS + 64 * W : sZ_ + 64 * W;
+            double diag[16];
+            if constexpr (p == D::NT - 1) {
+                constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
+                if (W == 0 && panel_last_dpp<D, NPIV_LAST>(sM, sInvD, lane) && lane == 0) sFlags[0] = 1;
+            } else if constexpr (p == 0) {
+                if (W < nshare0) {
+                    const int bad = panel_dpp<D, 1>(sM, sInvD, p, lane, W, diag, scratch);
+                    if (W == 0 && bad && lane == 0) sFlags[0] = 1;
+                }
+            } else if constexpr (W == 0) {
+                const int bad = panel_dpp<D, SL>(sM, sInvD, p, lane, 0, diag, scratch);
+                if (bad && lane == 0) sFlags[0] = 1;
+            }
+            if constexpr (p >= 1 && W >= 1) {
+                pipe_update<D, TPW, W, p - 1, 2>(acc, sM, lrow, crow);   // rest-update(p - 1)
+#ifndef VS_DIAG_NO_TINV
+                if constexpr (W == pipe_inverse_wave<D, TPW>(p)) {
+                    if constexpr (p - 1 < S::NXT)
+                        tile_inverse_dpp(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
+                    if constexpr (S::DUAL3 && p - 1 == D::PVT + 1)
+                        tile_inverse_dpp(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sM + (S::oDual3T0 - S::oM), lane);
+                }
+#endif
+            }
+            VS_P3_MARK(0);
+            __syncthreads();
+            VS_P3_MARK(1);
+            if constexpr (p + 1 < D::NT) {
+                if (W == 0 && lane < 16) {  // nobody reads tile (p, p) before the next barrier
+                    double* Tpp = sM + tile_off_c<D>(p, p) + lane * 17;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) Tpp[c] = diag[c];
+                    if (DEBUG && dbgL != nullptr) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c <= lane) dbgL[size_t(16 * p + lane) * D::NP + 16 * p + c] = diag[c];
+                    }
+                }
+                if constexpr (W >= 1) {
+                    if constexpr (p < PVT) {
+#pragma unroll
+                        for (int q = 0; q < TPW; ++q) {
+                            const int t = q * D::NWAVES + W;
+                            if (tab.holds(t, W) && tab.tj[t] == p && tab.ti[t] > p) {
+                                const double* T = sM + tile_off_c<D>(tab.ti[t], p) + crow;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
+                                if (tab.ti[t] == D::NT - 1 && (lane >> 4) == (GL & 3)) sW[16 * p + (lane & 15)] = -acc[q][GL >> 2];
+                            }
+                        }
+                    }
+                    pipe_update<D, TPW, W, p, 1>(acc, sM, lrow, crow);   // first-update(p), handed to LDS
+                }
+                VS_P3_MARK(2);
+                __syncthreads();
+                VS_P3_MARK(3);
+            }
+        });
+        return;
+    }
     // (a compile-time loop: the work lists below are indexed with p in constant expressions)
     static_for<0, D::NT>([&](auto pcst) __attribute__((always_inline)) {
         constexpr int p = decltype(pcst)::value;
@@ -913,7 +1089,11 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         }
         // a wavefront without panel rows inverts the diagonal tile finished one panel ago (its ring slot is intact
         // until the update of THIS panel hands column p+1 over): X_0..X_PVT for P5 and the dual box QP
+#ifndef VS_DIAG_NO_TINV   // (measurement builds: P3 without the tile inverses; results are garbage)
         if (W == (nshare > 1 ? D::NWAVES - 1 : 1) && p >= 1 && p - 1 < S::NXT)
+#else
+        if (false)
+#endif
             tile_inverse<D>(sM + tile_off_c<D>(p - 1, p - 1), sInvD + 16 * (p - 1), sXinv + (p - 1) * D::TS, lane);
         // three throttle tile rows: the box QP also wants the inverses of the other two corner diagonal tiles.  The second
         // one here, into the tile-shaped scratch the QP reads it from (that part of the ring is dead since the last joint
@@ -1016,11 +1196,11 @@ VS_DEV double row_sum4(double x) {
 // L_rq^T z_r to this wavefront's partial sum u_q, kept in registers; the partial sums of column r - 1 are published
 // before the barrier that ends step r (fixed summation order -> deterministic).  One workgroup barrier per tile row.
 // ------------------------------------------------------------------------------------------------
-template <class D, int TPW, int W>
+template <class D, int TPW, int W, bool PIPE = false>
 VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, double* __restrict__ sZ,
                          const double* __restrict__ sXinv, double* __restrict__ sU, int lane) {
-    constexpr WaveLists<D, TPW, W> wl{};
-    constexpr TileTab<D> tab{};
+    constexpr WaveLists<D, TPW, W, PIPE> wl{};
+    constexpr TileTab<D, PIPE> tab{};
     constexpr int PVT = D::PVT;
     double* myU = sU + W * D::NP;
     const int j = lane & 15, g4 = lane >> 4;
@@ -2081,7 +2261,7 @@ VS_DEV void p1s_contract(double* __restrict__ sm, int tid) {
 // afterwards: with the loads of a tile right in front of its instructions every tile pays LDS round trips; the
 // accumulators are not live yet, so there are registers for the raw operands of a group of tiles at once (the loads are
 // pinned in front of the arithmetic).
-template <class D, int TPW, int W>
+template <class D, int TPW, int W, bool PIPE = false>
 VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane) {
     using S = Smem<D>;
     constexpr int PVT = D::PVT, N = D::N, HC = D::HC, NV = D::NV;
@@ -2121,10 +2301,10 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     constexpr int q1 = q0 + G < TPW ? q0 + G : TPW;
     double raw[G][NJC][3];
     static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
-        constexpr TileTab<D> tab{};
+        constexpr TileTab<D, PIPE> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
-        if constexpr (t < D::NTRI) {
+        if constexpr (tab.forms(t, W)) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti < PVT) {
                 // H^(br, bc), br = blk0(ti) + g (this lane's k block), bc = the block of column j of tile column tj; stored
@@ -2157,12 +2337,12 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     __builtin_amdgcn_sched_barrier(0);
     double opa[G][NJC], opb[G][NJC];
     static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
-        constexpr TileTab<D> tab{};
+        constexpr TileTab<D, PIPE> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
 #pragma unroll
         for (int ks = 0; ks < NJC; ++ks) { opa[q - q0][ks] = 0.0; opb[q - q0][ks] = 0.0; }
-        if constexpr (t < D::NTRI) {
+        if constexpr (tab.forms(t, W)) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             // rows / columns of the dummy unknowns exist in the last joint tile row / column only (compile time)
             constexpr bool DUMMY_ROWS = 16 * ti + 16 > D::NUY, DUMMY_COLS = 16 * tj + 16 > D::NUY;
@@ -2189,11 +2369,11 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     });
     __builtin_amdgcn_sched_barrier(0);
     static_for<q0, q1>([&](auto qcst) __attribute__((always_inline)) {
-        constexpr TileTab<D> tab{};
+        constexpr TileTab<D, PIPE> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
         d4 c = d4{0.0, 0.0, 0.0, 0.0}, c2 = d4{0.0, 0.0, 0.0, 0.0};
-        if constexpr (t < D::NTRI) {
+        if constexpr (tab.forms(t, W)) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (tj < PVT) {
 #pragma unroll
@@ -2213,10 +2393,10 @@ VS_DEV void p1s_entries(d4 (&acc)[TPW], const double* __restrict__ sm, int lane)
     // the first stage any column of the tile can see (tau_i = 0 up to a column's first stage); a row that does not store
     // an earlier stage (Smem::ac_first) meets only such columns in the lower triangle and reads a zero there.
     static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
-        constexpr TileTab<D> tab{};
+        constexpr TileTab<D, PIPE> tab{};
         constexpr int q = decltype(qcst)::value;
         constexpr int t = q * D::NWAVES + W;
-        if constexpr (t < D::NTRI) {
+        if constexpr (tab.forms(t, W)) {
             constexpr int ti = tab.ti[t], tj = tab.tj[t];
             if constexpr (ti >= PVT && tj >= PVT) {
                 constexpr int K0 = tile_first_stage<D>(tj);   // first k-step (stage i' = i - 1)
@@ -2311,7 +2491,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     do {                                                                                    \
         if constexpr (STAMPS) {                                                             \
             unsigned long long* st_ = late_args()->stamps;                                  \
-            if (threadIdx.x == 0 && st_ != nullptr) st_[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+            if (tid == 0 && st_ != nullptr) st_[size_t(blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
         }                                                                                   \
     } while (0)
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -2330,7 +2510,16 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         }                                                                  \
     } while (0)
     using S = Smem<D>;
+#ifdef VS_DIAG_P3   // measurement build: the stamps instantiation takes the shipped (fused) path; no dumps, stamps 2 and 3 coincide
+    constexpr bool FUSED_DISPATCH = FORM == 1;
+#else
     constexpr bool FUSED_DISPATCH = FORM == 1 && !STAMPS;   // entries + P2 + P3 behind one wave dispatch (see P1)
+#endif
+    // the structured form runs P3 pipelined: wavefront 0 factors the panels, wavefronts 1..3 hold all tiles (TileTab, cholesky_wave)
+#ifndef VS_P3_PIPE
+#define VS_P3_PIPE 1
+#endif
+    constexpr bool PIPE = FORM == 1 && VS_P3_PIPE && VS_PANEL_DPP;
     // steps of the joint reduction that run in P0 (wavefront 3); the rest follows a generator chain in P1.  Long horizons
     // have ~9 k cycles of slack behind the generator chains, short ones ~3 k.
     constexpr int QR_P0_STEPS = D::STRUCT_LONG ? 1 : 2;
@@ -2367,6 +2556,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
     const int inst = blockIdx.x;
     if (inst >= batch) return;
+    // (Rotating which hardware wavefront plays which role with the workgroup index -- so that the serial role-0 phases of two
+    // co-resident workgroups do not share a SIMD -- measured no different at batch 4096: 392.3 us against 388.1.)
 #define VS_REFRESH_IDS()                                                                     \
     do {                                                                                     \
         unsigned m_ = ~0u;                                                                   \
@@ -2377,7 +2568,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
 
     // tiles of the lower triangle are dealt round-robin to the wavefronts: tile t -> wave t % NWAVES, slot t / NWAVES
     // (stage-sorted table in constant memory, padded with never-active dummies)
-    constexpr int TPW = (D::NTRI + D::NWAVES - 1) / D::NWAVES;
+    constexpr int TPW = TileTab<D, PIPE>::TPW;
 
     VS_STAMP(0);
     // ---------------------------------------------------------------- P0
@@ -2498,11 +2689,11 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             // the vector registers, and at the 2x horizon pushed other values into scratch to make room)
             auto tail = [&](auto wcst) __attribute__((always_inline)) {
                 constexpr int W = decltype(wcst)::value;
-                p1s_entries<D, TPW, W>(acc, smem, lane);
+                p1s_entries<D, TPW, W, PIPE>(acc, smem, lane);
                 __syncthreads();   // the LDS arrays of P1s lie under the ring P3 is about to fill
                 if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
                 const int ln = fresh_lane();
-                cholesky_wave<D, TPW, W, false, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, nullptr, ln,
+                cholesky_wave<D, TPW, W, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, nullptr, ln,
                                                       (ln >> 4) * 17 + (ln & 15), (ln & 15) * 17 + (ln >> 4), sZ);
             };
             switch (wave) {
@@ -2513,10 +2704,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             }
         } else {
         switch (wave) {
-            case 0: p1s_entries<D, TPW, 0>(acc, smem, lane); break;
-            case 1: p1s_entries<D, TPW, 1>(acc, smem, lane); break;
-            case 2: p1s_entries<D, TPW, 2>(acc, smem, lane); break;
-            default: p1s_entries<D, TPW, 3>(acc, smem, lane); break;
+            case 0: p1s_entries<D, TPW, 0, PIPE>(acc, smem, lane); break;
+            case 1: p1s_entries<D, TPW, 1, PIPE>(acc, smem, lane); break;
+            case 2: p1s_entries<D, TPW, 2, PIPE>(acc, smem, lane); break;
+            default: p1s_entries<D, TPW, 3, PIPE>(acc, smem, lane); break;
         }
         VS_TOC(2);
         __syncthreads();   // the LDS arrays of P1s lie under the ring P3 is about to fill
@@ -2743,8 +2934,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     if (STAMPS && dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            if (q * D::NWAVES + wave < D::NTRI) {
-                const int ti_q = kTileTab<D>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D>.tj[q * D::NWAVES + wave];
+            if (kTileTab<D, PIPE>.forms(q * D::NWAVES + wave, wave)) {
+                const int ti_q = kTileTab<D, PIPE>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D, PIPE>.tj[q * D::NWAVES + wave];
                 d4 tmp = acc[q];
                 if (ti_q == tj_q || ti_q >= PVT) {
 #pragma unroll
@@ -2764,17 +2955,17 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_REFRESH_IDS();
     if constexpr (!FUSED_DISPATCH)
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
-        case 0: cholesky_wave<D, TPW, 0, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
-        case 1: cholesky_wave<D, TPW, 1, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
-        case 2: cholesky_wave<D, TPW, 2, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
-        default: cholesky_wave<D, TPW, 3, STAMPS, PLDS>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 0: cholesky_wave<D, TPW, 0, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 1: cholesky_wave<D, TPW, 1, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        case 2: cholesky_wave<D, TPW, 2, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
+        default: cholesky_wave<D, TPW, 3, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLi, lane, crow, lrow, sZ); break;
     }
     static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
     if (STAMPS && dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int ti_q = kTileTab<D>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D>.tj[q * D::NWAVES + wave];
-            if (q * D::NWAVES + wave < D::NTRI && tj_q < PVT && ti_q > tj_q) {
+            const int ti_q = kTileTab<D, PIPE>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D, PIPE>.tj[q * D::NWAVES + wave];
+            if (kTileTab<D, PIPE>.holds(q * D::NWAVES + wave, wave) && tj_q < PVT && ti_q > tj_q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     dbgLi[size_t(16 * ti_q + (lane >> 4) + 4 * r) * D::NP + 16 * tj_q + (lane & 15)] = acc[q][r];
@@ -2974,10 +3165,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     // ---------------------------------------------------------------- P5 joints from the register-resident factor
     switch (wave) {
-        case 0: backsub_wave<D, TPW, 0>(acc, sW, sZ, sXinv, sU, lane); break;
-        case 1: backsub_wave<D, TPW, 1>(acc, sW, sZ, sXinv, sU, lane); break;
-        case 2: backsub_wave<D, TPW, 2>(acc, sW, sZ, sXinv, sU, lane); break;
-        default: backsub_wave<D, TPW, 3>(acc, sW, sZ, sXinv, sU, lane); break;
+        case 0: backsub_wave<D, TPW, 0, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
+        case 1: backsub_wave<D, TPW, 1, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
+        case 2: backsub_wave<D, TPW, 2, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
+        default: backsub_wave<D, TPW, 3, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
     }
     __syncthreads();
     if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
@@ -3174,7 +3365,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     VS_STAMP(9);
     if constexpr (STAMPS) {
         unsigned long long* st_ = late_args()->stamps;
-        if (threadIdx.x == 0 && st_ != nullptr) {
+        if (tid == 0 && st_ != nullptr) {
 #ifdef VS_DIAG_P3
             for (int i = 0; i < 4; ++i) t_acc[i] = vs_diag_p3[i];
 #endif

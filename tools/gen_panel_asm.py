@@ -145,32 +145,46 @@ class Stream:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# register maps
-A0, G0 = 100, 132                                             # a[c] = v[A0 + 2c : +1], g[c] = v[G0 + 2c : +1]
-Y, T, E, Z, W, INV, DP = 164, 166, 168, 170, 172, 174, 176
-LDA, STA, DGA, IVA = 178, 179, 180, 181                       # LDS byte addresses: row load, row store, diagonal row, 1 / L_jj
+# register maps (functions of the number of row slots S a lane carries)
 K375 = 76
 LAST_PANEL_PIVOTS = [8, 12]                                   # NZ - 16 (NT - 1) of the built horizons (vsmpc_device.hpp)
+SLOTS = 1
 
 
-def a(c):
-    return A0 + 2 * c
+class Map:
+    def __init__(self, slots):
+        self.S = slots
+        self.A0 = 100                                          # a[s][c] = v[A0 + 32 s + 2c : +1]
+        self.G0 = self.A0 + 32 * slots                         # g[c]
+        t = self.G0 + 32
+        self.Y, self.T, self.E, self.Z, self.W, self.INV, self.DP = t, t + 2, t + 4, t + 6, t + 8, t + 10, t + 12
+        self.DGA, self.IVA = t + 14, t + 15                    # LDS byte addresses: diagonal row, 1 / L_jj
+        self.LDA = [t + 16 + 2 * i for i in range(slots)]      # row load / store addresses per slot
+        self.STA = [t + 17 + 2 * i for i in range(slots)]
+        assert t + 16 + 2 * slots <= 256
+
+
+M = Map(1)
+
+
+def a(c, slot=0):
+    return M.A0 + 32 * slot + 2 * c
 
 
 def g(c):
-    return G0 + 2 * c
+    return M.G0 + 2 * c
 
 
-def prologue(s, with_a):
-    if with_a:
+def prologue(s, slots):
+    for sl in range(slots):
         for c in range(NP):
-            s.add("dsr", f"ds_read_b64 {vp(a(c))}, v{LDA} offset:{8 * c}", [f"v{LDA}"], regs("v", a(c)) + ["lgkm"])
+            s.add("dsr", f"ds_read_b64 {vp(a(c, sl))}, v{M.LDA[sl]} offset:{8 * c}", [f"v{M.LDA[sl]}"], regs("v", a(c, sl)) + ["lgkm"])
     for c in range(NP):
-        s.add("dsr", f"ds_read_b64 {vp(g(c))}, v{DGA} offset:{8 * c}", [f"v{DGA}"], regs("v", g(c)) + ["lgkm"])
+        s.add("dsr", f"ds_read_b64 {vp(g(c))}, v{M.DGA} offset:{8 * c}", [f"v{M.DGA}"], regs("v", g(c)) + ["lgkm"])
     s.add("smov", f"s_mov_b32 s{K375}, 0", [], [f"s{K375}"])
     s.add("smov", f"s_mov_b32 s{K375 + 1}, 0x3fd80000", [], [f"s{K375 + 1}"])
     # one wait for all loads (finer counts would let pivot 0 start earlier: ~100 cycles, not worth the bookkeeping)
-    allr = [r for c in range(NP) for r in regs("v", g(c))] + ([r for c in range(NP) for r in regs("v", a(c))] if with_a else [])
+    allr = [r for c in range(NP) for r in regs("v", g(c))] + [r for sl in range(slots) for c in range(NP) for r in regs("v", a(c, sl))]
     s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm"], allr)
 
 
@@ -181,6 +195,7 @@ def epilogue(s):
 
 def rsqrt_chain(s, d_src, d_regs):
     """fast_rsqrt of vsmpc_kernels.hip on the pivot in `d_src` -> INV"""
+    Y, T, E, Z, W, INV = M.Y, M.T, M.E, M.Z, M.W, M.INV
     s.add("rsq", f"v_rsq_f64_e32 {vp(Y)}, {d_src}", d_regs, regs("v", Y))
     s.add("mul", f"v_mul_f64 {vp(T)}, {d_src}, {vp(Y)}", d_regs + regs("v", Y), regs("v", T))
     s.add("fma", f"v_fma_f64 {vp(E)}, -{vp(T)}, {vp(Y)}, 1.0", regs("v", T) + regs("v", Y), regs("v", E))
@@ -189,10 +204,11 @@ def rsqrt_chain(s, d_src, d_regs):
     s.add("fma", f"v_fma_f64 {vp(INV)}, {vp(Z)}, {vp(W)}, {vp(Y)}", regs("v", Z) + regs("v", W) + regs("v", Y), regs("v", INV))
 
 
-def stream_dpp(npiv=NP, with_a=True):
-    """with_a = False: the diagonal tile alone (the last panel: npiv pivots, its other rows carried as ordinary rows)"""
+def stream_dpp(npiv=NP, slots=1):
+    """slots = 0: the diagonal tile alone (the last panel: npiv pivots, its other rows carried as ordinary rows)"""
     s = Stream()
-    prologue(s, with_a)
+    prologue(s, slots)
+    INV, DP = M.INV, M.DP
     for j in range(npiv):
         s.add("movdpp", f"v_mov_b64_dpp {vp(DP)}, {vp(g(j))} row_newbcast:{j} row_mask:0xf bank_mask:0xf", regs("v", g(j)), regs("v", DP),
               dpp_src=regs("v", g(j)))
@@ -200,17 +216,135 @@ def stream_dpp(npiv=NP, with_a=True):
         # 1 / L_jj for P5 and the tile inverses: the same value from every lane to the same address (wavefront 0; the others
         # are handed a dummy).  A non-positive pivot needs no bookkeeping: its reciprocal square root is NaN and so is
         # everything computed from it, down to the last pivot's, which the caller tests.
-        s.add("dsw", f"ds_write_b64 v{IVA}, {vp(INV)} offset:{8 * j}", [f"v{IVA}"] + regs("v", INV), ["lds"])
+        s.add("dsw", f"ds_write_b64 v{M.IVA}, {vp(INV)} offset:{8 * j}", [f"v{M.IVA}"] + regs("v", INV), ["lds"])
         s.add("mul", f"v_mul_f64 {vp(g(j))}, {vp(g(j))}, {vp(INV)}", regs("v", g(j)) + regs("v", INV), regs("v", g(j)))
-        if with_a:
-            s.add("mul", f"v_mul_f64 {vp(a(j))}, {vp(a(j))}, {vp(INV)}", regs("v", a(j)) + regs("v", INV), regs("v", a(j)))
-            s.add("dsw", f"ds_write_b64 v{STA}, {vp(a(j))} offset:{8 * j}", [f"v{STA}"] + regs("v", a(j)), ["lds"])
+        for sl in range(slots):
+            s.add("mul", f"v_mul_f64 {vp(a(j, sl))}, {vp(a(j, sl))}, {vp(INV)}", regs("v", a(j, sl)) + regs("v", INV), regs("v", a(j, sl)))
+            s.add("dsw", f"ds_write_b64 v{M.STA[sl]}, {vp(a(j, sl))} offset:{8 * j}", [f"v{M.STA[sl]}"] + regs("v", a(j, sl)), ["lds"])
         for c in range(j + 1, NP):
-            for dst, src1 in ((g(c), g(j)), (a(c), a(j))) if with_a else ((g(c), g(j)),):
+            for dst, src1 in [(g(c), g(j))] + [(a(c, sl), a(j, sl)) for sl in range(slots)]:
                 s.add("dpp", f"v_fmac_f64_dpp {vp(dst)}, -{vp(g(j))}, {vp(src1)} row_newbcast:{c} row_mask:0xf bank_mask:0xf",
                       regs("v", g(j)) + regs("v", src1) + regs("v", dst), regs("v", dst), dpp_src=regs("v", g(j)))
     epilogue(s)
     return s
+
+
+class RowsMap:
+    """rows-only stream: a[s][c], g[c], inv[j] pairs, addresses"""
+    def __init__(self, slots):
+        self.S = slots
+        self.A0 = 72
+        self.G0 = self.A0 + 32 * slots
+        self.I0 = self.G0 + 32
+        t = self.I0 + 32
+        self.DGA, self.IVA = t, t + 1
+        self.LDA = [t + 2 + 2 * i for i in range(slots)]
+        self.STA = [t + 3 + 2 * i for i in range(slots)]
+        assert t + 2 + 2 * slots <= 256
+
+
+def stream_rows(slots):
+    """The rows below an already factored diagonal tile: a <- a L^-T, column by column (right-looking, the operation order of
+    the fused stream: scale column j by 1 / L_jj, then a_c -= a_j l_cj for c > j).  The factored tile (row c of it in lane
+    16 r + c) and the sixteen 1 / L_jj come from LDS."""
+    R = RowsMap(slots)
+    s = Stream()
+    ar = lambda c, sl: R.A0 + 32 * sl + 2 * c
+    gr = lambda c: R.G0 + 2 * c
+    ir = lambda j: R.I0 + 2 * j
+    for c in range(NP):
+        s.add("dsr", f"ds_read_b64 {vp(gr(c))}, v{R.DGA} offset:{8 * c}", [f"v{R.DGA}"], regs("v", gr(c)) + ["lgkm"])
+    for j in range(NP):
+        s.add("dsr", f"ds_read_b64 {vp(ir(j))}, v{R.IVA} offset:{8 * j}", [f"v{R.IVA}"], regs("v", ir(j)) + ["lgkm"])
+    for sl in range(slots):
+        for c in range(NP):
+            s.add("dsr", f"ds_read_b64 {vp(ar(c, sl))}, v{R.LDA[sl]} offset:{8 * c}", [f"v{R.LDA[sl]}"], regs("v", ar(c, sl)) + ["lgkm"])
+    allr = [r for c in range(NP) for r in regs("v", gr(c)) + regs("v", ir(c))] + [r for sl in range(slots) for c in range(NP) for r in regs("v", ar(c, sl))]
+    s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm"], allr)
+    for j in range(NP):
+        for sl in range(slots):
+            s.add("mul", f"v_mul_f64 {vp(ar(j, sl))}, {vp(ar(j, sl))}, {vp(ir(j))}", regs("v", ar(j, sl)) + regs("v", ir(j)), regs("v", ar(j, sl)))
+            s.add("dsw", f"ds_write_b64 v{R.STA[sl]}, {vp(ar(j, sl))} offset:{8 * j}", [f"v{R.STA[sl]}"] + regs("v", ar(j, sl)), ["lds"])
+        for c in range(j + 1, NP):
+            for sl in range(slots):
+                s.add("dpp", f"v_fmac_f64_dpp {vp(ar(c, sl))}, -{vp(gr(j))}, {vp(ar(j, sl))} row_newbcast:{c} row_mask:0xf bank_mask:0xf",
+                      regs("v", gr(j)) + regs("v", ar(j, sl)) + regs("v", ar(c, sl)), regs("v", ar(c, sl)), dpp_src=regs("v", gr(j)))
+    epilogue(s)
+    return s, R
+
+
+def stream_inverse():
+    """X = L^-1 of a factored diagonal tile: the rows stream on the rows of the identity (lane c starts from e_c and ends with
+    row c of L^-T = column c of X), stored transposed: X[i][c] at x_addr + 8 (17 i + c), the tile layout the readers expect.
+    Lanes >= 16 repeat lanes 0..15 (same values to the same addresses)."""
+    R = RowsMap(1)
+    s = Stream()
+    ar = lambda c: R.A0 + 2 * c
+    gr = lambda c: R.G0 + 2 * c
+    ir = lambda j: R.I0 + 2 * j
+    LN = R.LDA[0]                      # lane & 15 (input)
+    for c in range(NP):
+        s.add("dsr", f"ds_read_b64 {vp(gr(c))}, v{R.DGA} offset:{8 * c}", [f"v{R.DGA}"], regs("v", gr(c)) + ["lgkm"])
+    for j in range(NP):
+        s.add("dsr", f"ds_read_b64 {vp(ir(j))}, v{R.IVA} offset:{8 * j}", [f"v{R.IVA}"], regs("v", ir(j)) + ["lgkm"])
+    for c in range(NP):
+        s.add("mov", f"v_mov_b32_e32 v{ar(c)}, 0", [], [f"v{ar(c)}"])
+        s.add("cmp", f"v_cmp_eq_u32_e32 vcc, {c}, v{LN}", [f"v{LN}"], ["vcc"])
+        s.add("cnd", f"v_cndmask_b32_e32 v{ar(c) + 1}, 0, v{R.STA[0] + 1}, vcc", ["vcc", f"v{R.STA[0] + 1}"], [f"v{ar(c) + 1}"])
+    allr = [r for c in range(NP) for r in regs("v", gr(c)) + regs("v", ir(c))]
+    s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm"], allr)
+    for j in range(NP):
+        s.add("mul", f"v_mul_f64 {vp(ar(j))}, {vp(ar(j))}, {vp(ir(j))}", regs("v", ar(j)) + regs("v", ir(j)), regs("v", ar(j)))
+        s.add("dsw", f"ds_write_b64 v{R.STA[0]}, {vp(ar(j))} offset:{8 * 17 * j}", [f"v{R.STA[0]}"] + regs("v", ar(j)), ["lds"])
+        for c in range(j + 1, NP):
+            s.add("dpp", f"v_fmac_f64_dpp {vp(ar(c))}, -{vp(gr(j))}, {vp(ar(j))} row_newbcast:{c} row_mask:0xf bank_mask:0xf",
+                  regs("v", gr(j)) + regs("v", ar(j)) + regs("v", ar(c)), regs("v", ar(c)), dpp_src=regs("v", gr(j)))
+    epilogue(s)
+    return s, R
+
+
+def function_inverse():
+    s, R = stream_inverse()
+    lines, cycles, ninstr, nops = s.emit()
+    body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
+    one_hi = R.STA[0] + 1
+    ins = [f'"{{v{R.DGA}}}"(diag_addr)', f'"{{v{R.IVA}}}"(invd_addr)', f'"{{v{R.LDA[0]}}}"(lane15)', f'"{{v{R.STA[0]}}}"(x_addr)',
+           f'"{{v{one_hi}}}"(0x3ff00000u)']
+    bound = set([f"v{R.DGA}", f"v{R.IVA}", f"v{R.LDA[0]}", f"v{R.STA[0]}", f"v{one_hi}"])
+    touched = set()
+    for n in s.nodes:
+        touched.update(r for r in n.rd + n.wr if r[0] in "vs" and r[1:].isdigit())
+    clob = sorted(touched - bound, key=lambda r: (r[0], int(r[1:])))
+    clobbers = ", ".join(f'"{r}"' for r in clob) + ', "vcc", "memory"'
+    text = ("\n// X = L^-1 of the factored diagonal tile at diag_addr (this lane's row: lane & 15), 1 / L_jj at invd_addr: the rows stream on\n"
+            "// the rows of the identity, stored transposed -- X[i][c] at x_addr + 8 (17 i), x_addr = &X[0][lane & 15].\n"
+            f"// {ninstr} instructions + {nops} wait states, {cycles} cycles in the generator's issue model.\n")
+    text += f"VS_DEV void panel_inverse_dpp(unsigned diag_addr, unsigned invd_addr, unsigned x_addr, int lane15) {{\n    asm volatile(\n{body}\n"
+    text += "        :\n        : " + ", ".join(ins) + "\n        : " + clobbers + ");\n}\n"
+    return text, ninstr, nops, cycles
+
+
+def function_rows(name, slots, comment):
+    s, R = stream_rows(slots)
+    lines, cycles, ninstr, nops = s.emit()
+    body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
+    ins = [f'"{{v{R.DGA}}}"(diag_addr)', f'"{{v{R.IVA}}}"(invd_addr)']
+    bound = set([f"v{R.DGA}", f"v{R.IVA}"])
+    sig = ""
+    for sl in range(slots):
+        ins += [f'"{{v{R.LDA[sl]}}}"(load_addr{sl})', f'"{{v{R.STA[sl]}}}"(store_addr{sl})']
+        bound.update([f"v{R.LDA[sl]}", f"v{R.STA[sl]}"])
+        sig += f"unsigned load_addr{sl}, unsigned store_addr{sl}, "
+    touched = set()
+    for n in s.nodes:
+        touched.update(r for r in n.rd + n.wr if r[0] in "vs" and r[1:].isdigit())
+    clob = sorted(touched - bound, key=lambda r: (r[0], int(r[1:])))
+    clobbers = ", ".join(f'"{r}"' for r in clob) + ', "memory"'
+    sig += "unsigned diag_addr, unsigned invd_addr"
+    text = f"\n// {comment}\n// {ninstr} instructions + {nops} wait states, {cycles} cycles in the generator's issue model.\n"
+    text += f"VS_DEV void {name}({sig}) {{\n    asm volatile(\n{body}\n"
+    text += "        :\n        : " + ", ".join(ins) + "\n        : " + clobbers + ");\n}\n"
+    return text, ninstr, nops, cycles
 
 
 HEADER = """// GENERATED by tools/gen_panel_asm.py -- do not edit (the why and the how are in that file's header).
@@ -219,12 +353,17 @@ HEADER = """// GENERATED by tools/gen_panel_asm.py -- do not edit (the why and t
 """
 
 
-def function(name, s, comment, with_a):
+def function(name, s, comment, slots):
     lines, cycles, ninstr, nops = s.emit()
     body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
-    outs = [f'"={{v[{g(c)}:{g(c) + 1}]}}"(g[{c}])' for c in range(NP)] + [f'"={{v[{INV}:{INV + 1}]}}"(inv_last)']
-    ins = [f'"{{v{DGA}}}"(diag_addr)', f'"{{v{IVA}}}"(invd_addr)'] + ([f'"{{v{LDA}}}"(load_addr)', f'"{{v{STA}}}"(store_addr)'] if with_a else [])
-    bound = set(regs("v", INV) + [f"v{DGA}", f"v{IVA}"] + ([f"v{LDA}", f"v{STA}"] if with_a else []))
+    outs = [f'"={{v[{g(c)}:{g(c) + 1}]}}"(g[{c}])' for c in range(NP)] + [f'"={{v[{M.INV}:{M.INV + 1}]}}"(inv_last)']
+    ins = [f'"{{v{M.DGA}}}"(diag_addr)', f'"{{v{M.IVA}}}"(invd_addr)']
+    bound = set(regs("v", M.INV) + [f"v{M.DGA}", f"v{M.IVA}"])
+    sig = ""
+    for sl in range(slots):
+        ins += [f'"{{v{M.LDA[sl]}}}"(load_addr{sl})', f'"{{v{M.STA[sl]}}}"(store_addr{sl})']
+        bound.update([f"v{M.LDA[sl]}", f"v{M.STA[sl]}"])
+        sig += f"unsigned load_addr{sl}, unsigned store_addr{sl}, "
     for c in range(NP):
         bound.update(regs("v", g(c)))
     touched = set()
@@ -232,7 +371,7 @@ def function(name, s, comment, with_a):
         touched.update(r for r in n.rd + n.wr if r[0] in "vs" and r[1:].isdigit())
     clob = sorted(touched - bound, key=lambda r: (r[0], int(r[1:])))
     clobbers = ", ".join(f'"{r}"' for r in clob) + ', "memory"'
-    sig = ("unsigned load_addr, unsigned store_addr, " if with_a else "") + "unsigned diag_addr, unsigned invd_addr, double (&g)[16], double& inv_last"
+    sig += "unsigned diag_addr, unsigned invd_addr, double (&g)[16], double& inv_last"
     text = f"\n// {comment}\n// {ninstr} instructions + {nops} wait states, {cycles} cycles in the generator's issue model.\n"
     text += f"VS_DEV void {name}({sig}) {{\n    asm volatile(\n{body}\n"
     text += "        : " + ", ".join(outs) + "\n        : " + ", ".join(ins) + "\n        : " + clobbers + ");\n}\n"
@@ -240,20 +379,34 @@ def function(name, s, comment, with_a):
 
 
 def main():
-    import sys
-    last = [int(x) for x in sys.argv[1:]] or LAST_PANEL_PIVOTS
+    global M
     text = HEADER
-    todo = [("panel16_dpp", stream_dpp(), "Lane 16 r + c carries the panel row at `load_addr` (stored, finished, to `store_addr`: the same row, or a 16-double\n"
-             "// dummy for rows beyond the matrix) and row c of the diagonal tile (`diag_addr`, returned factored in g).  1 / L_jj goes to\n"
-             "// invd_addr[j] (every lane writes it: a dummy for all wavefronts but one); inv_last = 1 / L_15,15 is NaN iff a pivot was\n"
-             "// not positive.", True)]
-    for npiv in last:
-        todo.append((f"panel_last{npiv}_dpp", stream_dpp(npiv, False), f"The last panel: {npiv} pivots in the diagonal tile, whose other rows are carried as ordinary "
-                     f"rows.\n// Lane 16 r + c carries row c (r = 0 is the copy that is stored); inv_last = 1 / L_{npiv - 1},{npiv - 1}.", False))
-    for name, s, comment, with_a in todo:
-        t, ninstr, nops, cycles = function(name, s, comment, with_a)
+    todo = []
+    for slots in (1, 2, 3):
+        todo.append((f"panel16x{slots}_dpp", 16, slots,
+                     f"{slots} row slot(s): lane 16 r + c carries the panel rows at load_addr0.. (stored, finished, to store_addr0..: the same row, or a\n"
+                     "// 16-double dummy for rows beyond the matrix) and row c of the diagonal tile (`diag_addr`, returned factored in g).  1 / L_jj\n"
+                     "// goes to invd_addr[j] (every lane writes it: a dummy for all wavefronts but one); inv_last = 1 / L_15,15 is NaN iff a pivot\n"
+                     "// was not positive."))
+    todo.append(("panel_diag16_dpp", 16, 0, "The diagonal tile alone, 16 pivots (the pipelined schedule factors it ahead of the rows below it: "
+                 "panel_rows*_dpp).\n// Lane 16 r + c carries row c; inv_last = 1 / L_15,15."))
+    for npiv in LAST_PANEL_PIVOTS:
+        todo.append((f"panel_last{npiv}_dpp", npiv, 0, f"The last panel: {npiv} pivots in the diagonal tile, whose other rows are carried as ordinary "
+                     f"rows.\n// Lane 16 r + c carries row c (r = 0 is the copy that is stored); inv_last = 1 / L_{npiv - 1},{npiv - 1}."))
+    for name, npiv, slots, comment in todo:
+        M = Map(max(slots, 1))
+        t, ninstr, nops, cycles = function(name, stream_dpp(npiv, slots), comment, slots)
         text += t
         print(f"{name}: {ninstr} instructions, {nops} wait states, modelled {cycles} cycles")
+    for slots in (1, 2, 3):
+        t, ninstr, nops, cycles = function_rows(f"panel_rows{slots}_dpp", slots,
+                                                f"{slots} row slot(s) below a diagonal tile that is already factored (in LDS at diag_addr, its 1 / L_jj at invd_addr): "
+                                                "a <- a L^-T.\n// Same operations in the same order as the fused streams above.")
+        text += t
+        print(f"panel_rows{slots}_dpp: {ninstr} instructions, {nops} wait states, modelled {cycles} cycles")
+    t, ninstr, nops, cycles = function_inverse()
+    text += t
+    print(f"panel_inverse_dpp: {ninstr} instructions, {nops} wait states, modelled {cycles} cycles")
     with open(OUT, "w") as f:
         f.write(text)
     print("->", OUT)

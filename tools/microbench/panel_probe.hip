@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void probe(const double* __restrict__ in, doubl
             sT[80 * 17 + lane] = inv_mine;
         }
     } else {
-        panel16_dpp(addr, addr, unsigned(reinterpret_cast<uintptr_t>(sT + (lane & 15) * 17)), unsigned(reinterpret_cast<uintptr_t>(sT + 80 * 17)), a, inv_last);
+        panel16x1_dpp(addr, addr, unsigned(reinterpret_cast<uintptr_t>(sT + (lane & 15) * 17)), unsigned(reinterpret_cast<uintptr_t>(sT + 80 * 17)), a, inv_last);
     }
     __syncthreads();
     if (lane < 16) {   // the factored diagonal tile goes back after the barrier, as in the solver
