@@ -1009,6 +1009,21 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                 if (bad && lane == 0) sFlags[0] = 1;
             }
             if constexpr (p >= 1 && W >= 1) {
+                // the finished tiles of column p - 1 come back into the registers that held them (the factor P5 reads; the
+                // gradient row -> right-hand side of the back-substitution).  Here, beside the stream, not between two streams:
+                // their ring slot stays intact until the barrier that ends this stream.
+                if constexpr (p - 1 < PVT) {
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) {
+                        const int t = q * D::NWAVES + W;
+                        if (tab.holds(t, W) && tab.tj[t] == p - 1 && tab.ti[t] > p - 1) {
+                            const double* T = sM + tile_off_c<D>(tab.ti[t], p - 1) + crow;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
+                            if (tab.ti[t] == D::NT - 1 && (lane >> 4) == (GL & 3)) sW[16 * (p - 1) + (lane & 15)] = -acc[q][GL >> 2];
+                        }
+                    }
+                }
                 pipe_update<D, TPW, W, p - 1, 2>(acc, sM, lrow, crow);   // rest-update(p - 1)
 #ifndef VS_DIAG_NO_TINV
                 if constexpr (W == pipe_inverse_wave<D, TPW>(p)) {
@@ -1033,21 +1048,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                             if (c <= lane) dbgL[size_t(16 * p + lane) * D::NP + 16 * p + c] = diag[c];
                     }
                 }
-                if constexpr (W >= 1) {
-                    if constexpr (p < PVT) {
-#pragma unroll
-                        for (int q = 0; q < TPW; ++q) {
-                            const int t = q * D::NWAVES + W;
-                            if (tab.holds(t, W) && tab.tj[t] == p && tab.ti[t] > p) {
-                                const double* T = sM + tile_off_c<D>(tab.ti[t], p) + crow;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) acc[q][r] = T[4 * r * 17];
-                                if (tab.ti[t] == D::NT - 1 && (lane >> 4) == (GL & 3)) sW[16 * p + (lane & 15)] = -acc[q][GL >> 2];
-                            }
-                        }
-                    }
-                    pipe_update<D, TPW, W, p, 1>(acc, sM, lrow, crow);   // first-update(p), handed to LDS
-                }
+                if constexpr (W >= 1) pipe_update<D, TPW, W, p, 1>(acc, sM, lrow, crow);   // first-update(p), handed to LDS
                 VS_P3_MARK(2);
                 __syncthreads();
                 VS_P3_MARK(3);
@@ -3179,25 +3180,40 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     // ---------------------------------------------------------------- P6 forward simulation + outputs
     // the output pointers: requested from the kernarg segment here, a phase ahead of their use (a scalar load is a
     // ~0.5 us round trip when it misses, and nothing else in P6 wants the scalar registers)
+#ifdef VS_DIAG_P6   // measurement build: P6 in four pieces (input terms / set-up + first step / other steps / outputs) -> t_acc[0..3]
+    for (int i = 0; i < 4; ++i) t_acc[i] = 0;
+    VS_TIC();
+#define VS_P6_TOC(i) VS_TOC(i)
+#else
+#define VS_P6_TOC(i) do { } while (0)
+#endif
     const SolveArgs* ka = late_args();
     double* xout = ka->xout;
     double* fmout = ka->fmout;
     int* status_out = ka->status_out;
     int* iters_out = ka->iters_out;
     // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c  (Bj U = R^T y in the reduced unknowns)
-    for (int e = tid; e < NX * D::N; e += D::BLOCK) {
-        const int k = e / NX, r = e - k * NX;
-        const int jb = joint_block_of_stage<D>(k);
-        const int tb = throttle_block_of_stage<D>(k);
-        const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
-        double f = sC[r];
+    // (straight-line rounds with clamped indices: the loads of all rounds are in flight together; as a loop with a per-thread
+    // trip count the rounds ran one LDS round trip after the other)
+    {
+        constexpr int NE = NX * D::N, RND = (NE + D::BLOCK - 1) / D::BLOCK;
 #pragma unroll
-        for (int c = 0; c < NJC; ++c) f += sBj[r * NJ + c] * sZ[NJC * jb + c];
+        for (int rd = 0; rd < RND; ++rd) {
+            const int e = tid + rd * D::BLOCK, ec = e < NE ? e : NE - 1;
+            const int k = ec / NX, r = ec - k * NX;
+            const int jb = joint_block_of_stage<D>(k);
+            const int tb = throttle_block_of_stage<D>(k);
+            const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
+            double f = sC[r];
 #pragma unroll
-        for (int c = 0; c < NTH; ++c) f += sBt[r * NTH + c] * sV[vq + c];
-        sF[e] = f;
+            for (int c = 0; c < NJC; ++c) f += sBj[r * NJ + c] * sZ[NJC * jb + c];
+#pragma unroll
+            for (int c = 0; c < NTH; ++c) f += sBt[r * NTH + c] * sV[vq + c];
+            if (e < NE) sF[e] = f;
+        }
     }
     __syncthreads();
+    VS_P6_TOC(0);
     {
         // The three links of the cascade (jets -> momenta -> CoM / RPY + error integrators; systemDynamicsVSMPC.cpp:
         // 79-103,288-319,384-429) run in THREE wavefronts, one chunk of CHK stages apart: step s = jets of chunk s (wavefront
@@ -3205,7 +3221,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // (wavefront 2); a workgroup barrier per step hands the trajectories over through sX.  NCH + 2 steps instead of the
         // 3 NCH chunk-lengths one wavefront needs for the links in series (through v19: 8.1 k cycles at the paper horizon,
         // 17.0 k at the 2x horizon; now 7.1 k / 11.6 k).
-        constexpr int CHK = D::N > 20 ? 9 : 6, NCH = (D::N + CHK - 1) / CHK;
+#ifndef VS_P6_CHK
+#define VS_P6_CHK (D::N > 20 ? 9 : 6)
+#endif
+        constexpr int CHK = VS_P6_CHK, NCH = (D::N + CHK - 1) / CHK;
         // chain states (registers of the owning lanes, alive across the steps)
         double jT = 0.0, jTd = 0.0, jon = 0.0, ja = 0.0, jb = 0.0;
         double Sk[9], hh[3] = {0.0, 0.0, 0.0};
@@ -3243,6 +3262,16 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             joint_expand<D>(smem + S::oQR, sZ + NJC * lane, u8);
 #pragma unroll
             for (int i = 0; i < 8; ++i) sU[NJ * lane + i] = u8[i];
+        }
+        // ... and sends the input part of the primal on its way to HBM while the cascade runs (the state part follows at the end)
+        if (wave == 3 && xout != nullptr) {
+            double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
+            for (int i = lane; i < D::NUO / 2; i += 64) xo[D::NXS / 2 + i] = make_double2(sU[2 * i], sU[2 * i + 1]);
+            if (lane < D::NV / 2) {  // reference order v_0..v_{NVB-1}
+                const int e = 2 * lane, b = e >> 2, c = e & 3;
+                const int q = b == 0 ? D::NV - 4 + c : 4 * (b - 1) + c;
+                xo[(D::NXS + D::NUO) / 2 + lane] = make_double2(sV[q], sV[q + 1]);
+            }
         }
         static_for<0, NCH + 2>([&](auto scst) __attribute__((always_inline)) {
             constexpr int st = decltype(scst)::value;
@@ -3331,21 +3360,18 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 }
             }
             if constexpr (st + 1 < NCH + 2) __syncthreads();
+            if constexpr (st == 0) VS_P6_TOC(1);
         });
     }
     __syncthreads();
+    VS_P6_TOC(2);
     VS_STAMP(8);
     VS_REFRESH_IDS();
 
     if (xout != nullptr) {
         double2* xo = reinterpret_cast<double2*>(xout + size_t(inst) * D::NVAR);  // 16 B per lane stores
         for (int i = tid; i < D::NXS / 2; i += D::BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
-        for (int i = tid; i < D::NUO / 2; i += D::BLOCK) xo[D::NXS / 2 + i] = make_double2(sU[2 * i], sU[2 * i + 1]);
-        if (tid < D::NV / 2) {  // reference order v_0..v_{NVB-1}
-            const int e = 2 * tid, b = e >> 2, c = e & 3;
-            const int q = b == 0 ? D::NV - 4 + c : 4 * (b - 1) + c;
-            xo[(D::NXS + D::NUO) / 2 + tid] = make_double2(sV[q], sV[q + 1]);
-        }
+        // (the joint increments and the throttles left from wavefront 3 during the cascade)
     }
     if (fmout != nullptr && tid < VSMPC_FM_SIZE) {
         double v;
@@ -3362,11 +3388,12 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         status_out[inst] = st;
         if (iters_out != nullptr) iters_out[inst] = sFlags[2];
     }
+    VS_P6_TOC(3);
     VS_STAMP(9);
     if constexpr (STAMPS) {
         unsigned long long* st_ = late_args()->stamps;
         if (tid == 0 && st_ != nullptr) {
-#ifdef VS_DIAG_P3
+#if defined(VS_DIAG_P3) && !defined(VS_DIAG_P6)
             for (int i = 0; i < 4; ++i) t_acc[i] = vs_diag_p3[i];
 #endif
             t_acc[5] = __builtin_amdgcn_s_memrealtime() - rt0;

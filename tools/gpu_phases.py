@@ -22,7 +22,9 @@ for wl, B in ((("hover", 256), ("takeoff", 256)) if len(_s.argv) > 1 else (("hov
     for i, n in enumerate(names):
         print(f"  {n:38s} median {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f}  share {100*np.median(d[:, i])/np.median(tot):5.1f}%")
     sub = ["P1 recursion / chain (wave 0)", "P1 barrier wait", "P1 MFMA / entries", "P1 set-up / contraction (structured form)", "start stamp (s_memrealtime)", "wall time, 10 ns ticks (s_memrealtime)"]
-    if "VS_DIAG_P3" in os.environ.get("VSMPC_HIPCC_FLAGS", ""):   # measurement build: P3 seen from wavefront 0
+    if "VS_DIAG_P6" in os.environ.get("VSMPC_HIPCC_FLAGS", ""):
+        sub[:4] = ["P6 input terms of all stages", "P6 set-up, joint expansion, first step", "P6 remaining steps", "P6 outputs to HBM"]
+    elif "VS_DIAG_P3" in os.environ.get("VSMPC_HIPCC_FLAGS", ""):   # measurement build: P3 seen from wavefront 0
         sub[:4] = ["P3 panel streams (wave 0)", "P3 wait behind the stream", "P3 tile store + reload + trailing update", "P3 wait behind the update"]
     for i, n in enumerate(sub):
         print(f"    {n:36s} median {np.median(st[:, 10 + i]):9.0f}")
