@@ -2511,11 +2511,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         }                                                                  \
     } while (0)
     using S = Smem<D>;
-#ifdef VS_DIAG_P3   // measurement build: the stamps instantiation takes the shipped (fused) path; no dumps, stamps 2 and 3 coincide
-    constexpr bool FUSED_DISPATCH = FORM == 1;
-#else
-    constexpr bool FUSED_DISPATCH = FORM == 1 && !STAMPS;   // entries + P2 + P3 behind one wave dispatch (see P1)
-#endif
+    constexpr bool FUSED_DISPATCH = FORM == 1;   // entries + P2 + P3 behind one wave dispatch (see P1)
     // the structured form runs P3 pipelined: wavefront 0 factors the panels, wavefronts 1..3 hold all tiles (TileTab, cholesky_wave)
 #ifndef VS_P3_PIPE
 #define VS_P3_PIPE 1
@@ -2552,11 +2548,16 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     // wave from its scalar register) instead of being carried through the kernel: a value that is live from the first
     // to the last instruction is the register allocator's favourite spill candidate, and every reload from scratch is a
     // global-memory round trip on the critical path of a latency-bound workgroup.
-    int tid = threadIdx.x;
-    int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
     const int inst = blockIdx.x;
     if (inst >= batch) return;
+    int tid = threadIdx.x;
+    int lane = tid & 63;
+#ifdef VS_ROLE_ROT   // measurement builds: rotate the roles of the hardware wavefronts with the workgroup index
+    const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + ((inst >> 8) & 3)) & 3);
+    tid = (wave << 6) | lane;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-dependent branches become s_cbranch
+#endif
     // (Rotating which hardware wavefront plays which role with the workgroup index -- so that the serial role-0 phases of two
     // co-resident workgroups do not share a SIMD -- measured no different at batch 4096: 392.3 us against 388.1.)
 #define VS_REFRESH_IDS()                                                                     \
@@ -2688,14 +2689,66 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             // the shipped structured form: ONE wave dispatch for the entries, P2 and P3 -- the accumulator tiles are born and
             // factored inside one branch, no join in between (at a join the allocator moved the tiles of a wavefront through
             // the vector registers, and at the 2x horizon pushed other values into scratch to make room)
+            // (The diagnostic instantiation takes the same path; its dumps -- condensed Hessian before, factor after P3 -- and the
+            // stamps of the P1 / P2 / P3 boundaries sit inside the branch.)
             auto tail = [&](auto wcst) __attribute__((always_inline)) {
                 constexpr int W = decltype(wcst)::value;
                 p1s_entries<D, TPW, W, PIPE>(acc, smem, lane);
+                VS_TOC(2);
                 __syncthreads();   // the LDS arrays of P1s lie under the ring P3 is about to fill
+                VS_STAMP(2);
+                double* dbgLw = nullptr;
+                if constexpr (STAMPS) {
+                    constexpr TileTab<D, PIPE> tab{};
+                    double* dbgM = late_args()->dbgM;
+                    double* dbgL = late_args()->dbgL;
+                    dbgLw = dbgL != nullptr ? dbgL + size_t(inst) * D::NP * D::NP : nullptr;
+                    if (dbgM != nullptr) {   // debug/parity only: the augmented condensed Hessian before factorisation, from registers
+                        const int ln = fresh_lane();
+                        static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+                            constexpr int q = decltype(qcst)::value;
+                            constexpr int t = q * D::NWAVES + W;
+                            if constexpr (tab.forms(t, W)) {
+                                constexpr int ti_q = tab.ti[t], tj_q = tab.tj[t];
+                                d4 tmp = acc[q];
+                                if constexpr (ti_q == tj_q || ti_q >= D::PVT) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        tmp[r] += input_cost_term<D>(sCfg, smem + S::oQR + S::QR_GY, sVprev, 16 * ti_q + (ln >> 4) + 4 * r,
+                                                                     16 * tj_q + (ln & 15));
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int gr = 16 * ti_q + (ln >> 4) + 4 * r, gc = 16 * tj_q + (ln & 15);
+                                    if (gc <= gr) dbgM[size_t(inst) * D::NP * D::NP + size_t(gr) * D::NP + gc] = tmp[r];
+                                }
+                            }
+                        });
+                    }
+                }
+                VS_STAMP(3);
                 if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
                 const int ln = fresh_lane();
-                cholesky_wave<D, TPW, W, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, nullptr, ln,
+                cholesky_wave<D, TPW, W, STAMPS, PLDS, PIPE>(sCfg, acc, Lb, sInvD, smem + S::oQR + S::QR_GY, sVprev, sFlags, sXinv, sW, dbgLw, ln,
                                                       (ln >> 4) * 17 + (ln & 15), (ln & 15) * 17 + (ln >> 4), sZ);
+                if constexpr (STAMPS) {
+                    if (dbgLw != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
+                        constexpr TileTab<D, PIPE> tab{};
+                        const int l2 = fresh_lane();
+                        static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+                            constexpr int q = decltype(qcst)::value;
+                            constexpr int t = q * D::NWAVES + W;
+                            if constexpr (tab.holds(t, W)) {
+                                constexpr int ti_q = tab.ti[t], tj_q = tab.tj[t];
+                                if constexpr (tj_q < D::PVT && ti_q > tj_q) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        dbgLw[size_t(16 * ti_q + (l2 >> 4) + 4 * r) * D::NP + 16 * tj_q + (l2 & 15)] = acc[q][r];
+                                }
+                            }
+                        });
+                    }
+                }
             };
             switch (wave) {
                 case 0: tail(std::integral_constant<int, 0>{}); break;
@@ -2918,7 +2971,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         }
         VS_TIC();
     }
-    VS_STAMP(2);
+    if constexpr (!FUSED_DISPATCH) VS_STAMP(2);   // (the fused branch stamps its own P1 / P2 / P3 boundaries)
     VS_REFRESH_IDS();
     if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);   // long horizons: see pin_tiles_agpr
 
@@ -2932,7 +2985,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     double* dbgM = STAMPS ? late_args()->dbgM : nullptr;
     double* dbgL = STAMPS ? late_args()->dbgL : nullptr;
     double* dbgLi = dbgL != nullptr ? dbgL + size_t(inst) * D::NP * D::NP : nullptr;
-    if (STAMPS && dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
+    if (STAMPS && !FUSED_DISPATCH && dbgM != nullptr) {  // debug/parity only: the augmented condensed Hessian before factorisation, from registers
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
             if (kTileTab<D, PIPE>.forms(q * D::NWAVES + wave, wave)) {
@@ -2952,7 +3005,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             }
         }
     }
-    VS_STAMP(3);
+    if constexpr (!FUSED_DISPATCH) VS_STAMP(3);
     VS_REFRESH_IDS();
     if constexpr (!FUSED_DISPATCH)
     switch (wave) {  // scalar dispatch: every wavefront runs its own straight-line copy, same barrier count
@@ -2963,13 +3016,15 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     static_assert(D::NWAVES == 4, "wave-specialised phases are instantiated for four wavefronts");
     if (STAMPS && dbgLi != nullptr) {  // debug/parity only: the factor; diagonal tiles were written while they were panels
+        if constexpr (!FUSED_DISPATCH) {
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int ti_q = kTileTab<D, PIPE>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D, PIPE>.tj[q * D::NWAVES + wave];
-            if (kTileTab<D, PIPE>.holds(q * D::NWAVES + wave, wave) && tj_q < PVT && ti_q > tj_q) {
+            for (int q = 0; q < TPW; ++q) {
+                const int ti_q = kTileTab<D, PIPE>.ti[q * D::NWAVES + wave], tj_q = kTileTab<D, PIPE>.tj[q * D::NWAVES + wave];
+                if (kTileTab<D, PIPE>.holds(q * D::NWAVES + wave, wave) && tj_q < PVT && ti_q > tj_q) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dbgLi[size_t(16 * ti_q + (lane >> 4) + 4 * r) * D::NP + 16 * tj_q + (lane & 15)] = acc[q][r];
+                    for (int r = 0; r < 4; ++r)
+                        dbgLi[size_t(16 * ti_q + (lane >> 4) + 4 * r) * D::NP + 16 * tj_q + (lane & 15)] = acc[q][r];
+                }
             }
         }
         for (int e = tid; e < (D::NP - 16 * PVT) * (D::NP - 16 * PVT); e += D::BLOCK) {  // throttle corner, from LDS
