@@ -998,7 +998,11 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
             double diag[16];
             if constexpr (p == D::NT - 1) {
                 constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
-                if (W == 0 && panel_last_dpp<D, NPIV_LAST>(sM, sInvD, lane) && lane == 0) sFlags[0] = 1;
+                if constexpr (NPIV_LAST == 8 || NPIV_LAST == 12) {   // the generated streams (tools/gen_panel_asm.py LAST_PANEL_PIVOTS)
+                    if (W == 0 && panel_last_dpp<D, NPIV_LAST>(sM, sInvD, lane) && lane == 0) sFlags[0] = 1;
+                } else {                                              // any other horizon: the C++ stream
+                    if (W == 0 && panel_factor<D, 1, NPIV_LAST, false, false>(sM, sInvD, p, lane, 0, diag, scratch) && lane == 0) sFlags[0] = 1;
+                }
             } else if constexpr (p == 0) {
                 if (W < nshare0) {
                     const int bad = panel_dpp<D, 1>(sM, sInvD, p, lane, W, diag, scratch);
@@ -1075,7 +1079,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
         {
             constexpr int NPIV_LAST = D::NZ - 16 * (D::NT - 1);
             if (p == D::NT - 1) {
-                if constexpr (VS_PANEL_DPP) {
+                if constexpr (VS_PANEL_DPP && (NPIV_LAST == 8 || NPIV_LAST == 12)) {
                     if (W == 0 && panel_last_dpp<D, NPIV_LAST>(sM, sInvD, lane) && lane == 0) sFlags[0] = 1;
                 } else {
                     if (W == 0 && panel_factor<D, 1, NPIV_LAST, false, PLDS>(sM, sInvD, p, lane, 0, diag, sCol) && lane == 0) sFlags[0] = 1;

@@ -8,7 +8,7 @@ PKG=paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_amd
 H=${1:-17,7,12}; shift || true
 Q=${QUICK_OUT:-exp/quick}
 rm -rf $Q/src && mkdir -p $Q/src/$PKG/csrc $Q/src/include
-cp $PKG/csrc/*.hip $PKG/csrc/*.hpp $Q/src/$PKG/csrc/
+cp $PKG/csrc/*.hip $PKG/csrc/*.hpp $PKG/csrc/*.inc $Q/src/$PKG/csrc/
 cp include/*.h $Q/src/include/
 echo "X($(echo $H | sed 's/,/, /g'))" > $Q/src/$PKG/csrc/vsmpc_horizons.def
 S=$Q/src/$PKG/csrc

@@ -90,7 +90,7 @@ def main():
              f"VGPR {meta['vgpr']} + AGPR {meta['agpr']}", "",
              f"- SQ_INSTS_MFMA {med['SQ_INSTS_MFMA']:.0f} = {out['mfma_instructions_per_instance']:.0f} per instance; "
              f"SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 = {out['mfma_flops_per_instance']/1e6:.2f} MFLOP executed per instance "
-             f"(F_alg = 3.086 MFLOP at the paper horizon)",
+             f"(F_alg = {'6.17 MFLOP at the 2x horizon' if 'Dims<34' in meta['kernel'] else '3.086 MFLOP at the paper horizon'})",
              f"- SQ_VALU_MFMA_BUSY_CYCLES {med['SQ_VALU_MFMA_BUSY_CYCLES']:.0f} (= 64 per instruction); kernel busy "
              f"{busy_cyc:.0f} cycles (SQ_BUSY_CYCLES / 32 SEs)",
              f"- **mfma_busy_frac = {out['mfma_busy_frac']:.3f}** of all SIMD-cycles of the launch",
