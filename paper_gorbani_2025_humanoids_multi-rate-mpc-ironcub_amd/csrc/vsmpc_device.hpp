@@ -70,7 +70,7 @@ struct Dims {
     //   * a ring of two panel columns (column p while it is factored / applied, column p+1 being handed over),
     //   * the throttle corner (tile rows and columns >= PVT: the box QP works on it), and
     //   * the inverses X_p of the joint diagonal tiles (back-substitution without a chain).
-    // That is 15 + 3 + 7 tiles at the paper horizon instead of the 36 + 8 + 15 of the LDS-resident factor, which is
+    // That is 13 + 3 + 6 tiles at the paper horizon instead of the 28 + 6 + 13 of an LDS-resident factor, which is
     // what lets two workgroups share one CU (<= 80 KB each).  Nothing lives in global memory for any horizon.
     static constexpr int PVT = NU >> 4;                      // first tile row that contains a throttle row
     static constexpr int RING_A = NT;                        // tiles of an even panel column (at most NT)
