@@ -287,24 +287,25 @@ def test_structured_and_syrk_condensing_agree(mpc, solver_mod, synth, layout):
         mpc.set_kernel_form(7)
 
 
-def test_panel_stream_variants_agree(mpc, synth, layout):
-    """P3's panel streams exist in two variants (panel_factor in csrc/vsmpc_kernels.hip): pivot columns broadcast with
-    v_readlane (a lone workgroup per CU) or through LDS (two workgroups per CU, picked once the batch exceeds the CU
-    count); VSMPC_PANEL overrides the choice.  Same arithmetic in the same order: bit-identical results."""
-    import os
+def test_solves_are_deterministic_and_independent_of_batch_position(mpc, synth, layout):
+    """Every 16-lane row of a panel wavefront factors its own copy of the diagonal tile, panel 0 is shared by several wavefronts
+    that each do the same, and the tiles are dealt to the wavefronts at compile time (cholesky_wave, tools/gen_panel_asm.py):
+    nothing depends on timing or on where in a launch an instance sits.  Bit-identical results for the same records solved
+    twice, in another order, and inside a launch with two workgroups per CU."""
     cfg = layout.paper_config()
     recs = np.concatenate([synth.make_batch(cfg, 40, workload="takeoff"), synth.make_batch(cfg, 40, workload="montecarlo")])
-    out = {}
-    try:
-        for variant in ("readlane", "lds"):
-            os.environ["VSMPC_PANEL"] = variant
-            out[variant] = mpc.solve(recs)
-    finally:
-        os.environ.pop("VSMPC_PANEL", None)
-    a, b = out["readlane"], out["lds"]
+    a = mpc.solve(recs)
     assert (a[2] == layout.STATUS_SOLVED).all()
-    for u, v in zip(a, b):
+    b = mpc.solve(recs)
+    perm = np.random.default_rng(5).permutation(len(recs))
+    c = mpc.solve(recs[perm])
+    big = np.concatenate([recs[perm]] * 8)          # 640 instances: more than one workgroup per CU
+    d = mpc.solve(big)
+    for u, v, w, z in zip(a, b, c, d):
         np.testing.assert_array_equal(u, v)
+        np.testing.assert_array_equal(u[perm], w)
+        for rep in range(8):
+            np.testing.assert_array_equal(u[perm], z[rep * len(recs):(rep + 1) * len(recs)])
 
 
 def test_edge_cases(mpc, solver_mod, synth, layout, ref):
