@@ -38,7 +38,7 @@ OUT = os.path.join(ROOT, "paper_gorbani_2025_humanoids_multi-rate-mpc-ironcub_am
 
 NP = 16
 # (issue cycles, cycles until the result can be consumed without a stall) per class: lone wavefront
-COST = {"fma": (6, 10), "mul": (6, 10), "min": (6, 10), "dpp": (6, 12), "movdpp": (6, 12), "rl": (5, 34), "rsq": (10, 28),
+COST = {"bar": (16, 16), "fma": (6, 10), "mul": (6, 10), "min": (6, 10), "dpp": (6, 12), "movdpp": (6, 12), "rl": (5, 34), "rsq": (10, 28),
         "cmp": (4, 8), "cnd": (4, 6), "mov": (4, 6), "smov": (2, 4), "dsr": (5, 70), "dsw": (5, 5), "wait": (2, 2)}
 
 
@@ -63,9 +63,11 @@ class Node:
 class Stream:
     def __init__(self):
         self.nodes = []
+        self.edges = []          # (first, then): scheduling constraints beyond the register dependencies
 
     def add(self, kind, text, rd, wr, dpp_src=()):
         self.nodes.append(Node(kind, text, rd, wr, dpp_src))
+        return self.nodes[-1]
 
     def link(self):
         last_w, readers = {}, {}
@@ -83,6 +85,8 @@ class Stream:
             for w in n.wr:
                 last_w[w] = n
                 readers[w] = []
+        for a_, b_ in self.edges:
+            b_.deps.add(a_)
         for n in self.nodes:
             n.deps.discard(n)
             for d in n.deps:
@@ -90,8 +94,17 @@ class Stream:
 
     def schedule(self):
         self.link()
-        for n in reversed(self.nodes):
-            n.prio = COST[n.kind][1] + max((s.prio for s in n.succ), default=0)
+        done = set()
+
+        def prio(n):      # longest latency-weighted path to the end (the extra edges can point backwards in list order)
+            if id(n) not in done:
+                done.add(id(n))
+                n.prio = COST[n.kind][1] + max((prio(q) for q in n.succ), default=0)
+            return n.prio
+        import sys
+        sys.setrecursionlimit(10000)
+        for n in self.nodes:
+            prio(n)
         pending = {id(n): len(n.deps) for n in self.nodes}
         ready_at = {id(n): 0 for n in self.nodes}
         avail = [n for n in self.nodes if not n.deps]
@@ -147,21 +160,31 @@ class Stream:
 # ---------------------------------------------------------------------------------------------------------------------
 # register maps (functions of the number of row slots S a lane carries)
 K375 = 76
+# (row slots, pivot behind which the barrier sits).  Empty: the schedule that used them (docs/experiments/
+# r04_p3_in_stream_barrier.diff; e.g. [(1, 5), (2, 5), (2, 9), (3, 9)]) measured no faster than two plain barriers per panel
+BARRIER_VARIANTS = []
 LAST_PANEL_PIVOTS = [8, 12]                                   # NZ - 16 (NT - 1) of the built horizons (vsmpc_device.hpp)
 SLOTS = 1
 
 
 class Map:
-    def __init__(self, slots):
+    def __init__(self, slots, keep_inv=0):
+        """keep_inv: pivots whose 1 / L_jj gets a register pair of its own (the barrier variants: the rows join late and scale
+        with it then)"""
         self.S = slots
-        self.A0 = 100                                          # a[s][c] = v[A0 + 32 s + 2c : +1]
+        need = 32 * slots + 32 + 14 + 2 + 2 * slots + 2 * keep_inv
+        self.A0 = min(100, (256 - need) & ~1)                  # a[s][c] = v[A0 + 32 s + 2c : +1]
         self.G0 = self.A0 + 32 * slots                         # g[c]
         t = self.G0 + 32
         self.Y, self.T, self.E, self.Z, self.W, self.INV, self.DP = t, t + 2, t + 4, t + 6, t + 8, t + 10, t + 12
         self.DGA, self.IVA = t + 14, t + 15                    # LDS byte addresses: diagonal row, 1 / L_jj
         self.LDA = [t + 16 + 2 * i for i in range(slots)]      # row load / store addresses per slot
         self.STA = [t + 17 + 2 * i for i in range(slots)]
-        assert t + 16 + 2 * slots <= 256
+        self.INVX = [t + 16 + 2 * slots + 2 * j for j in range(keep_inv)]
+        assert t + 16 + 2 * slots + 2 * keep_inv <= 256
+
+    def inv(self, j):
+        return self.INVX[j] if j < len(self.INVX) else self.INV
 
 
 M = Map(1)
@@ -175,14 +198,24 @@ def g(c):
     return M.G0 + 2 * c
 
 
-def prologue(s, slots):
-    for sl in range(slots):
-        for c in range(NP):
-            s.add("dsr", f"ds_read_b64 {vp(a(c, sl))}, v{M.LDA[sl]} offset:{8 * c}", [f"v{M.LDA[sl]}"], regs("v", a(c, sl)) + ["lgkm"])
+def prologue(s, slots, bar=False):
+    """Loads.  bar: the rows below the diagonal tile are requested only after the workgroup barrier inside the stream (the
+    wavefronts that complete them arrive there later than the one tile this stream starts with)."""
     for c in range(NP):
         s.add("dsr", f"ds_read_b64 {vp(g(c))}, v{M.DGA} offset:{8 * c}", [f"v{M.DGA}"], regs("v", g(c)) + ["lgkm"])
     s.add("smov", f"s_mov_b32 s{K375}, 0", [], [f"s{K375}"])
     s.add("smov", f"s_mov_b32 s{K375 + 1}, 0x3fd80000", [], [f"s{K375 + 1}"])
+    if bar:
+        s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm"], [r for c in range(NP) for r in regs("v", g(c))])
+        s.bar = s.add("bar", "s_barrier", [], ["bar"])     # (held back until 1 / L_KB,KB is known: Stream.edges)
+        for sl in range(slots):
+            for c in range(NP):
+                s.add("dsr", f"ds_read_b64 {vp(a(c, sl))}, v{M.LDA[sl]} offset:{8 * c}", [f"v{M.LDA[sl]}", "bar"], regs("v", a(c, sl)) + ["lgkm2"])
+        s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm2"], [r for sl in range(slots) for c in range(NP) for r in regs("v", a(c, sl))])
+        return
+    for sl in range(slots):
+        for c in range(NP):
+            s.add("dsr", f"ds_read_b64 {vp(a(c, sl))}, v{M.LDA[sl]} offset:{8 * c}", [f"v{M.LDA[sl]}"], regs("v", a(c, sl)) + ["lgkm"])
     # one wait for all loads (finer counts would let pivot 0 start earlier: ~100 cycles, not worth the bookkeeping)
     allr = [r for c in range(NP) for r in regs("v", g(c))] + [r for sl in range(slots) for c in range(NP) for r in regs("v", a(c, sl))]
     s.add("wait", "s_waitcnt lgkmcnt(0)", ["lgkm"], allr)
@@ -193,26 +226,32 @@ def epilogue(s):
     s.add("wait", "s_waitcnt lgkmcnt(0)", ["lds"], ["lds"])
 
 
-def rsqrt_chain(s, d_src, d_regs):
+def rsqrt_chain(s, d_src, d_regs, INV=None):
     """fast_rsqrt of vsmpc_kernels.hip on the pivot in `d_src` -> INV"""
-    Y, T, E, Z, W, INV = M.Y, M.T, M.E, M.Z, M.W, M.INV
+    Y, T, E, Z, W = M.Y, M.T, M.E, M.Z, M.W
+    INV = M.INV if INV is None else INV
     s.add("rsq", f"v_rsq_f64_e32 {vp(Y)}, {d_src}", d_regs, regs("v", Y))
     s.add("mul", f"v_mul_f64 {vp(T)}, {d_src}, {vp(Y)}", d_regs + regs("v", Y), regs("v", T))
     s.add("fma", f"v_fma_f64 {vp(E)}, -{vp(T)}, {vp(Y)}, 1.0", regs("v", T) + regs("v", Y), regs("v", E))
     s.add("mul", f"v_mul_f64 {vp(Z)}, {vp(Y)}, {vp(E)}", regs("v", Y) + regs("v", E), regs("v", Z))
     s.add("fma", f"v_fma_f64 {vp(W)}, {sp(K375)}, {vp(E)}, 0.5", regs("s", K375) + regs("v", E), regs("v", W))
-    s.add("fma", f"v_fma_f64 {vp(INV)}, {vp(Z)}, {vp(W)}, {vp(Y)}", regs("v", Z) + regs("v", W) + regs("v", Y), regs("v", INV))
+    return s.add("fma", f"v_fma_f64 {vp(INV)}, {vp(Z)}, {vp(W)}, {vp(Y)}", regs("v", Z) + regs("v", W) + regs("v", Y), regs("v", INV))
 
 
-def stream_dpp(npiv=NP, slots=1):
-    """slots = 0: the diagonal tile alone (the last panel: npiv pivots, its other rows carried as ordinary rows)"""
+def stream_dpp(npiv=NP, slots=1, bar_after=None):
+    """slots = 0: the diagonal tile alone (the last panel: npiv pivots, its other rows carried as ordinary rows).
+    bar_after = KB: the stream starts on the diagonal tile alone and joins a workgroup barrier once 1 / L_KB,KB is known; the
+    rows below are loaded behind it, and their share of pivots 0 .. KB is caught up from there (same instructions, later)."""
     s = Stream()
-    prologue(s, slots)
-    INV, DP = M.INV, M.DP
+    prologue(s, slots, bar_after is not None)
+    DP = M.DP
     for j in range(npiv):
+        INV = M.inv(j)
         s.add("movdpp", f"v_mov_b64_dpp {vp(DP)}, {vp(g(j))} row_newbcast:{j} row_mask:0xf bank_mask:0xf", regs("v", g(j)), regs("v", DP),
               dpp_src=regs("v", g(j)))
-        rsqrt_chain(s, vp(DP), regs("v", DP))
+        inv_node = rsqrt_chain(s, vp(DP), regs("v", DP), INV)
+        if bar_after == j:
+            s.edges.append((inv_node, s.bar))
         # 1 / L_jj for P5 and the tile inverses: the same value from every lane to the same address (wavefront 0; the others
         # are handed a dummy).  A non-positive pivot needs no bookkeeping: its reciprocal square root is NaN and so is
         # everything computed from it, down to the last pivot's, which the caller tests.
@@ -388,14 +427,22 @@ def main():
                      "// 16-double dummy for rows beyond the matrix) and row c of the diagonal tile (`diag_addr`, returned factored in g).  1 / L_jj\n"
                      "// goes to invd_addr[j] (every lane writes it: a dummy for all wavefronts but one); inv_last = 1 / L_15,15 is NaN iff a pivot\n"
                      "// was not positive."))
+    for slots, kb in BARRIER_VARIANTS:
+        todo.append((f"panel16x{slots}_b{kb}_dpp", 16, (slots, kb),
+                     f"{slots} row slot(s), with a workgroup barrier INSIDE: the stream starts when the diagonal tile is ready, factors pivots 0 .. {kb} of it,\n"
+                     f"// joins the barrier that says the rows below are complete (s_barrier: every other wavefront of the workgroup must execute a\n"
+                     "// matching one), loads them and catches their share up.  Otherwise panel16xS_dpp."))
     todo.append(("panel_diag16_dpp", 16, 0, "The diagonal tile alone, 16 pivots (the pipelined schedule factors it ahead of the rows below it: "
                  "panel_rows*_dpp).\n// Lane 16 r + c carries row c; inv_last = 1 / L_15,15."))
     for npiv in LAST_PANEL_PIVOTS:
         todo.append((f"panel_last{npiv}_dpp", npiv, 0, f"The last panel: {npiv} pivots in the diagonal tile, whose other rows are carried as ordinary "
                      f"rows.\n// Lane 16 r + c carries row c (r = 0 is the copy that is stored); inv_last = 1 / L_{npiv - 1},{npiv - 1}."))
     for name, npiv, slots, comment in todo:
-        M = Map(max(slots, 1))
-        t, ninstr, nops, cycles = function(name, stream_dpp(npiv, slots), comment, slots)
+        kb = None
+        if isinstance(slots, tuple):
+            slots, kb = slots
+        M = Map(max(slots, 1), 0 if kb is None else kb + 1)
+        t, ninstr, nops, cycles = function(name, stream_dpp(npiv, slots, kb), comment, slots)
         text += t
         print(f"{name}: {ninstr} instructions, {nops} wait states, modelled {cycles} cycles")
     for slots in (1, 2, 3):
