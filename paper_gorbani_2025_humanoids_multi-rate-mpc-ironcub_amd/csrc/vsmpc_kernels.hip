@@ -4,6 +4,9 @@
 // (IMPCProblem.cpp:150-298, variableSamplingMPC.cpp:88-112) with a structure-exploiting exact solve:
 //
 //   P0 linearise   A, Bj, Bt, c in LDS                       (systemDynamicsVSMPC.cpp:79-103,288-319,384-429)
+//                  + joint reduction: a joint block acts on the dynamics through [Lambda_lin; Lambda_ang] (6 x 8) only, so
+//                  SIX unknowns per block are condensed (Householder QR of (Lambda W^-1/2)^T, p0_joint_reduction); the two
+//                  others have a closed form                  (constraintsVSMPC.cpp:85-103, costsVSMPC.cpp:375-381,564-591)
 //   P1 condense    jet thrust sensitivities first (one two-state recursion per throttle column, four for the affine
 //                  column).  Structured form (P1s, the default where Dims::STRUCT_P1): forward / adjoint recursions on
 //                  three generator columns per joint block, the throttle columns and the affine column, one lane per
@@ -17,10 +20,12 @@
 //                                                            (constraintsVSMPC.cpp:76-131, costsVSMPC.cpp:166-178)
 //   P2 augment     M = C + R, gradient row                   (costsVSMPC.cpp:375-409,468-487,558-592)
 //   P3 cholesky    right-looking LL^T on 16x16 tiles; the trailing matrix AND the finished factor stay in registers,
-//                  LDS holds a ring of two panel columns + the throttle corner; trailing updates on MFMA; a panel is
-//                  factored lane = row (pivots broadcast with v_readlane, or through LDS once two workgroups share a
-//                  CU) by up to three wavefronts that each repeat the diagonal tile and take 48 of the rows below; a
-//                  wavefront without panel rows inverts the finished diagonal tiles (X_p)
+//                  LDS holds a ring of two panel columns + the throttle corner; trailing updates on MFMA.  A panel stream
+//                  is generated assembly (vsmpc_panel_asm.inc <- tools/gen_panel_asm.py): every lane carries panel rows
+//                  and, replicated per 16-lane row, a row of the diagonal tile; the pivot column is broadcast inside the FMA
+//                  (v_fmac_f64 DPP row_newbcast).  Structured form: PIPELINED -- wavefront 0 factors panel p while
+//                  wavefronts 1..3, which hold all tiles, apply panel p - 1 and invert diagonal tile p - 1 (cholesky_wave,
+//                  TileTab<D, PIPE>); SYRK form: the panel shared by up to three wavefronts, all four update
 //   P4 box QP      backward pass over the throttle tiles with only the hold pin; only if a bound is violated: block
 //                  principal pivoting in one wavefront, dual form on P = X^T X for few violated bounds, primal form
 //                  on the Schur complement otherwise, small systems in registers   (constraintsVSMPC.cpp:338-365)
@@ -34,9 +39,10 @@
 //
 // Measured on MI355X (profiles/r01_microbench_*.txt, tools/microbench/lat_probe.hip): v_mfma_f64_16x16x4_f64 issues
 // every 64 cycles per SIMD (77.7 TFLOP/s chip-wide, already with one wavefront per SIMD), a dependent one every ~95; FP64
-// VALU work does not hide under it (shared FP64 datapath); a dependent vector instruction issues every 8-10 cycles, a
-// v_readlane takes ~32 cycles to land, v_readlane pair + FMA ~21.6 per update.  Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core
-// streams carry nothing but operand loads.
+// VALU work does not hide under it (shared FP64 datapath); a lone wavefront issues one FP64 vector instruction per ~5.7
+// cycles whatever the dependencies (a serial stream costs its instruction count), a v_readlane takes ~32 cycles to land.
+// Hence: every index is compile-time or scalar, LDS offsets are immediates, and the matrix-core streams carry nothing but
+// operand loads.
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
