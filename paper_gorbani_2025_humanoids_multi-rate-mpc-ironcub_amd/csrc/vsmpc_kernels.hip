@@ -217,8 +217,12 @@ struct Smem {
     static constexpr int oSZero = D::STRUCT_LONG ? oW : oSRefC + 12 * D::NREF;
     static_assert(!D::STRUCT_LONG || sizeZero <= 2 * D::NP, "zeros fit the w and z vectors");
     static constexpr int endP1s = D::STRUCT_LONG ? oSRefC + 12 * D::NREF : oSZero + sizeZero;
+    // P3, pipelined schedule: one tile behind the ring and the corner -- the diagonal tile of the NEXT panel column as its holder
+    // has it (updates of all earlier panels applied), parked there so that wavefront 0 can apply the current panel to it
+    // itself the moment its stream ends (cholesky_wave).  The arrays of P1s that lie there are dead by then.
+    static constexpr int oNextDiag = oM + sizeM;
     static constexpr int total_syrk = oR + (sizeY > sizeM ? sizeY : sizeM);
-    static constexpr int total_struct = D::STRUCT_P1 ? (endP1s > oR + sizeM ? endP1s : oR + sizeM) : total_syrk;
+    static constexpr int total_struct = D::STRUCT_P1 ? (endP1s > oNextDiag + D::TS ? endP1s : oNextDiag + D::TS) : total_syrk;
     // both forms share one carve-up; a horizon with the structured form never launches the SYRK form unless asked to
     // (vsmpc_set_kernel_form), so each form gets its own size
     static constexpr int total = total_syrk;
@@ -692,7 +696,9 @@ VS_DEV unsigned lds_addr(const double* q) { return unsigned(reinterpret_cast<uin
 // `scratch` = 32 doubles of this wavefront nobody reads: rows beyond the matrix and the other wavefronts' 1 / L_jj end there.
 // Returns non-zero if a pivot was not positive (its reciprocal square root is NaN, and then so is everything after it down
 // to the last one).
-template <class D, int S = 1>
+// KB > 0: the variant with a workgroup barrier inside (s_barrier behind pivot KB of the diagonal tile, the rows below are
+// loaded behind it): the caller's other wavefronts execute a matching __syncthreads().
+template <class D, int S = 1, int KB = 0>
 VS_DEV int panel_dpp(double* __restrict__ Lb, double* __restrict__ sInvD, int p, int lane, int w, double (&diag)[16],
                       double* scratch) {
     unsigned ld[S], st[S];
@@ -707,9 +713,14 @@ VS_DEV int panel_dpp(double* __restrict__ Lb, double* __restrict__ sInvD, int p,
     const unsigned iv = lds_addr(w == 0 ? sInvD + 16 * p : scratch + 16);
     double inv_last;
     static_assert(S >= 1 && S <= 3, "tools/gen_panel_asm.py generates one, two and three row slots");
-    if constexpr (S == 1) panel16x1_dpp(ld[0], st[0], dg, iv, diag, inv_last);
-    else if constexpr (S == 2) panel16x2_dpp(ld[0], st[0], ld[1], st[1], dg, iv, diag, inv_last);
-    else panel16x3_dpp(ld[0], st[0], ld[1], st[1], ld[2], st[2], dg, iv, diag, inv_last);
+    static_assert(KB == 0 || (S == 1 && KB == 3) || (S == 2 && (KB == 3 || KB == 6)) || (S == 3 && KB == 6), "tools/gen_panel_asm.py BARRIER_VARIANTS");
+    if constexpr (S == 1 && KB == 0) panel16x1_dpp(ld[0], st[0], dg, iv, diag, inv_last);
+    else if constexpr (S == 2 && KB == 0) panel16x2_dpp(ld[0], st[0], ld[1], st[1], dg, iv, diag, inv_last);
+    else if constexpr (S == 3 && KB == 0) panel16x3_dpp(ld[0], st[0], ld[1], st[1], ld[2], st[2], dg, iv, diag, inv_last);
+    else if constexpr (S == 1) panel16x1_b3_dpp(ld[0], st[0], dg, iv, diag, inv_last);
+    else if constexpr (S == 2 && KB == 3) panel16x2_b3_dpp(ld[0], st[0], ld[1], st[1], dg, iv, diag, inv_last);
+    else if constexpr (S == 2) panel16x2_b6_dpp(ld[0], st[0], ld[1], st[1], dg, iv, diag, inv_last);
+    else panel16x3_b6_dpp(ld[0], st[0], ld[1], st[1], ld[2], st[2], dg, iv, diag, inv_last);
     return !(inv_last == inv_last);
 }
 // The last panel (one wavefront): NPIV pivots, the remaining rows of the tile (gradient row, padding) are ordinary rows.
@@ -851,15 +862,35 @@ __shared__ unsigned long long vs_diag_p3[4];
 // independent v_mfma_f64_16x16x4_f64 issue every 64 cycles, a dependent one every ~95 -- since the pipelined schedule put
 // these chains on the critical path (first) or beside a panel stream that is no longer than they are (rest), that matters.
 // The operands of the next pair are requested before the chains of the current one.
-template <class D, int TPW, int W, int PP, int KIND>
-constexpr int pipe_count() {
-    constexpr WaveLists<D, TPW, W, true> wl{};
-    return KIND == 1 ? wl.nfirst[PP] : wl.nrest[PP];
-}
+// KIND 1: the tiles of column PP + 1 (3: only its diagonal tile, 4: all but the diagonal tile), 2: everything right of it
 template <class D, int TPW, int W, int PP, int KIND>
 constexpr int pipe_slot(int a) {
     constexpr WaveLists<D, TPW, W, true> wl{};
-    return KIND == 1 ? wl.first[PP][a] : wl.rest[PP][a];
+    constexpr TileTab<D, true> tab{};
+    if (KIND == 2) return a < wl.nrest[PP] ? wl.rest[PP][a] : -1;
+    int k = 0;
+    for (int b = 0; b < wl.nfirst[PP]; ++b) {
+        const int t = wl.first[PP][b] * D::NWAVES + W;
+        const bool dg = tab.ti[t] == tab.tj[t];
+        if (KIND == 1 || (KIND == 3 && dg) || (KIND == 4 && !dg)) {
+            if (k == a) return wl.first[PP][b];
+            ++k;
+        }
+    }
+    return -1;
+}
+template <class D, int TPW, int W, int PP, int KIND>
+constexpr int pipe_count() {
+    int n = 0;
+    while (n < TPW && pipe_slot<D, TPW, W, PP, KIND>(n) >= 0) ++n;
+    return n;
+}
+// the most tiles any of the wavefronts 1..3 has to update between the barrier that says "diagonal tile of column PP + 1
+// ready" and the one inside the next panel stream (decides how far into the stream that barrier sits)
+template <class D, int TPW, int PP>
+constexpr int pipe_max_others() {
+    const int n1 = pipe_count<D, TPW, 1, PP, 4>(), n2 = pipe_count<D, TPW, 2, PP, 4>(), n3 = pipe_count<D, TPW, 3, PP, 4>();
+    return n1 > n2 ? (n1 > n3 ? n1 : n3) : (n2 > n3 ? n2 : n3);
 }
 template <class D, int TPW, int W, int PP, int KIND>
 VS_DEV void pipe_update(d4 (&acc)[TPW], double* __restrict__ sM, int lrow, int crow) {
@@ -886,12 +917,26 @@ VS_DEV void pipe_update(d4 (&acc)[TPW], double* __restrict__ sM, int lrow, int c
             request(std::integral_constant<int, a + 2>{});
             constexpr int q0 = pipe_slot<D, TPW, W, PP, KIND>(a), q1 = pipe_slot<D, TPW, W, PP, KIND>(a + 1 < n ? a + 1 : a);
             constexpr int b = (a >> 1) & 1;
+            if constexpr (a + 1 < n) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][ks], lb[b][0][ks], acc[q0], 0, 0, 0);
-                if constexpr (a + 1 < n) acc[q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][1][ks], lb[b][1][ks], acc[q1], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][ks], lb[b][0][ks], acc[q0], 0, 0, 0);
+                    acc[q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][1][ks], lb[b][1][ks], acc[q1], 0, 0, 0);
+                }
+            } else if constexpr (KIND == 2 || KIND == 1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][ks], lb[b][0][ks], acc[q0], 0, 0, 0);
+            } else {   // (long horizons) a lone tile on the critical path: two chains of two, summed (a dependent step costs ~95 cycles, not 64)
+                d4 c2 = d4{0.0, 0.0, 0.0, 0.0};
+                acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][0], lb[b][0][0], acc[q0], 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][1], lb[b][0][1], c2, 0, 0, 0);
+                acc[q0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][2], lb[b][0][2], acc[q0], 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[b][0][3], lb[b][0][3], c2, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q0][r] += c2[r];
             }
-            if constexpr (KIND == 1) {
+            if constexpr (KIND != 2) {
                 static_for<0, 2>([&](auto ucst) __attribute__((always_inline)) {
                     constexpr int u = decltype(ucst)::value;
                     if constexpr (a + u < n) {
@@ -984,15 +1029,26 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
     // Wavefront 0 factors panel p while wavefronts 1..3 -- which hold all the tiles -- apply panel p - 1 to everything right of
     // column p.  Only the update of column p + 1 itself (`first`: one or two tiles per wavefront) stands between two streams:
     //     wavefront 0                         wavefronts 1..3
-    //     stream(p)                           rest-update(p - 1): tiles (i, j), j > p, with column p - 1;  one of them: X_(p-1)
+    //     stream(p): pivots 0..KB of the      first-update(p - 1) of the tiles (i, p), i > p, handed to LDS
+    //     diagonal tile ...
+    //     ----- s_barrier inside the stream = barrier: column p complete
+    //     ... the rows below join, rest of    column p - 1's finished tiles -> registers; rest-update(p - 1): tiles (i, j), j > p,
+    //     the stream                          with column p - 1;  one of them: X_(p-1)
     //     ----------------------------------- barrier: column p factored, the ring slot of column p - 1 free
-    //     store the diagonal tile             column p's finished tiles -> registers; first-update(p): tiles (i, p + 1) with
-    //                                         column p, handed to LDS (ring slot of column p - 1 / the corner)
-    //     ----------------------------------- barrier: column p + 1 complete
+    //     store the diagonal tile             first-update(p) of tile (p + 1, p + 1) with column p, handed to LDS
+    //     ----------------------------------- barrier: diagonal tile of column p + 1 complete
     // Panel 0 has no update beside it: it is shared like in the plain schedule (one 64-row stream per wavefront); from
     // panel 1 on wavefront 0 carries all rows below the diagonal tile in one to three row slots.
     if constexpr (PIPE) {
         static_assert(VS_PANEL_DPP, "the pipelined schedule is built on the DPP panel streams");
+        // Long horizons (one workgroup per CU; panel columns up to eleven tiles high): the diagonal tile of the next column is
+        // updated by wavefront 0 itself and the other tiles arrive under the first pivots of its stream (ND, below).  Measured:
+        // 1,637 -> 1,596 us per 4096 instances at the 2x horizon; at the paper horizon, where a column is at most six tiles
+        // and the other wavefronts are done with them in the time wavefront 0 needs for its one, 37.4 us against 37.2.
+#ifndef VS_P3_NEXTDIAG
+#define VS_P3_NEXTDIAG (D::WG_PER_CU == 1)
+#endif
+        constexpr bool ND = VS_P3_NEXTDIAG;
         static_for<0, D::NT>([&](auto pcst) __attribute__((always_inline)) {
             constexpr int p = decltype(pcst)::value;
             if constexpr (D::WG_PER_CU == 1) pin_tiles_agpr<TPW>(acc);
@@ -1015,9 +1071,32 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                     if (W == 0 && bad && lane == 0) sFlags[0] = 1;
                 }
             } else if constexpr (W == 0) {
-                const int bad = panel_dpp<D, SL>(sM, sInvD, p, lane, 0, diag, scratch);
+                // the stream starts on the diagonal tile alone; the barrier that says "the rows below are complete" is the
+                // s_barrier INSIDE it (behind pivot KB: far enough in for the other wavefronts' one or two -- long horizons:
+                // up to four -- tiles of this column), matched by the __syncthreads() behind their first-update below
+                constexpr int KB = !ND ? 0 : (SL == 3 ? 6 : (SL == 1 ? 3 : (pipe_max_others<D, TPW, p - 1>() > 2 ? 6 : 3)));
+                const int bad = panel_dpp<D, SL, KB>(sM, sInvD, p, lane, 0, diag, scratch);
                 if (bad && lane == 0) sFlags[0] = 1;
             }
+            // the holder of tile (p + 1, p + 1) parks it in LDS (all earlier panels applied): wavefront 0 applies panel p to it
+            // itself as soon as its stream has ended, no wavefront has to be waited for (not for the last panel, which is that
+            // one tile: its holder updates it as before)
+            auto park_next_diag = [&]() __attribute__((always_inline)) {
+                if constexpr (ND && W >= 1 && p + 1 < D::NT - 1) {
+                    static_for<0, TPW>([&](auto qcst) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qcst)::value;
+                        constexpr int t = q * D::NWAVES + W;
+                        if constexpr (tab.holds(t, W)) {
+                            if constexpr (tab.ti[t] == p + 1 && tab.tj[t] == p + 1) {
+                                double* T = sM + (S::oNextDiag - S::oM) + crow;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) T[4 * r * 17] = acc[q][r];
+                            }
+                        }
+                    });
+                }
+            };
+            if constexpr (p == 0) park_next_diag();
             if constexpr (p >= 1 && W >= 1) {
                 // the finished tiles of column p - 1 come back into the registers that held them (the factor P5 reads; the
                 // gradient row -> right-hand side of the back-substitution).  Here, beside the stream, not between two streams:
@@ -1035,6 +1114,7 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                     }
                 }
                 pipe_update<D, TPW, W, p - 1, 2>(acc, sM, lrow, crow);   // rest-update(p - 1)
+                park_next_diag();
 #ifndef VS_DIAG_NO_TINV
                 if constexpr (W == pipe_inverse_wave<D, TPW>(p)) {
                     if constexpr (p - 1 < S::NXT)
@@ -1058,10 +1138,40 @@ VS_DEV void cholesky_wave(const double* __restrict__ sCfg, d4 (&acc)[TPW], doubl
                             if (c <= lane) dbgL[size_t(16 * p + lane) * D::NP + 16 * p + c] = diag[c];
                     }
                 }
-                if constexpr (W >= 1) pipe_update<D, TPW, W, p, 1>(acc, sM, lrow, crow);   // first-update(p), handed to LDS
-                VS_P3_MARK(2);
-                __syncthreads();
-                VS_P3_MARK(3);
+                if constexpr (ND && p + 1 < D::NT - 1) {
+                    // first-update(p).  Wavefront 0: the diagonal tile of column p + 1, from its parked copy, written where the
+                    // next stream loads it (same wavefront: LDS operations stay in order, no barrier) -- two chains of two matrix
+                    // instructions.  Wavefronts 1..3: the other tiles of the column, handed to LDS, then the barrier that
+                    // wavefront 0 meets INSIDE its next stream, behind the first pivots of the diagonal tile.
+                    if constexpr (W == 0) {
+                        const double* Ljp = sM + tile_off_c<D>(p + 1, p) + lrow;
+                        const double* Cn = sM + (S::oNextDiag - S::oM) + crow;
+                        double lb[4];
+                        d4 c, c2 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) lb[ks] = Ljp[4 * ks];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c[r] = Cn[4 * r * 17];
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-lb[0], lb[0], c, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-lb[1], lb[1], c2, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-lb[2], lb[2], c, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-lb[3], lb[3], c2, 0, 0, 0);
+                        double* T = sM + tile_off_c<D>(p + 1, p + 1) + crow;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[4 * r * 17] = c[r] + c2[r];
+                        VS_P3_MARK(2);
+                    } else {
+                        pipe_update<D, TPW, W, p, 4>(acc, sM, lrow, crow);
+                        __syncthreads();
+                    }
+                } else {
+                    // short horizons, and the last panel (one tile) everywhere: the holders apply panel p to the whole column,
+                    // a barrier, wavefront 0 factors it
+                    if constexpr (W >= 1) pipe_update<D, TPW, W, p, 1>(acc, sM, lrow, crow);
+                    VS_P3_MARK(2);
+                    __syncthreads();
+                    VS_P3_MARK(3);
+                }
             }
         });
         return;

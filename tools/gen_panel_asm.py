@@ -160,9 +160,7 @@ class Stream:
 # ---------------------------------------------------------------------------------------------------------------------
 # register maps (functions of the number of row slots S a lane carries)
 K375 = 76
-# (row slots, pivot behind which the barrier sits).  Empty: the schedule that used them (docs/experiments/
-# r04_p3_in_stream_barrier.diff; e.g. [(1, 5), (2, 5), (2, 9), (3, 9)]) measured no faster than two plain barriers per panel
-BARRIER_VARIANTS = []
+BARRIER_VARIANTS = [(1, 3), (2, 3), (2, 6), (3, 6)]        # (row slots, pivot behind which the barrier sits)
 LAST_PANEL_PIVOTS = [8, 12]                                   # NZ - 16 (NT - 1) of the built horizons (vsmpc_device.hpp)
 SLOTS = 1
 
