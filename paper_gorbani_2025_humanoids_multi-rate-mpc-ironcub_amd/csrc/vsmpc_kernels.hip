@@ -1358,7 +1358,7 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) zz[i] = zt[i];
-            if (W == 0 && j == 0) {
+            if (W == (PIPE ? 1 : 0) && j == 0) {   // (PIPE: wavefront 0 is not here, see p5_wave0_jets)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sZ[16 * r + g4 + 4 * i] = zz[i];
             }
@@ -1385,6 +1385,77 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
             __syncthreads();
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P5, wavefront 0 of the pipelined schedule (kernel v29).  It holds no tile, so the back-substitution has nothing for it to do
+// but meet its NT - 1 barriers -- and the first link of P6's cascade, the jets, depends on the throttles only, which are final
+// since P4: their input terms and their whole two-state recursion (systemDynamicsVSMPC.cpp:384-429) run here, beside P5,
+// CHJ stages per barrier interval.  P6 then starts at the momenta, one pipeline step shorter.  (Wavefront 0's slot of the
+// partial sums is zeroed once; wavefront 1 stores z.)
+// ------------------------------------------------------------------------------------------------
+template <class D>
+VS_DEV void p5_wave0_jets(double* __restrict__ smem, int lane) {
+    using S = Smem<D>;
+    // stages per barrier interval: spread over all NT - 1 of them, so that no barrier of P5 waits for this wavefront
+    constexpr int CHJ = (D::N + D::NT - 2) / (D::NT - 1), NCJ = (D::N + CHJ - 1) / CHJ;
+    static_assert(NCJ <= D::NT - 1, "the jets fit the barrier intervals of P5");
+    const double* sIn = smem + S::oIn;
+    const double* sA = smem + S::oA;
+    const double* sBt = smem + S::oBt;
+    const double* sC = smem + S::oC;
+    const double* sZ = smem + S::oZ;
+    const double* sDt = smem + S::oDt;
+    double* sU = smem + S::oU;
+    double* sX = smem + S::oX;
+    for (int i = lane; i < D::NP; i += 64) sU[i] = 0.0;
+    const int jl = lane < NTH ? lane : 0;     // (lanes >= NTH shadow jet 0 and store nothing)
+    const double jon = sA[(12 + jl) * NX + 16 + jl], ja = sA[(16 + jl) * NX + 12 + jl], jb = sA[(16 + jl) * NX + 16 + jl];
+    const double c12 = sC[12 + jl], c16 = sC[16 + jl];
+    double bt12[NTH], bt16[NTH];
+#pragma unroll
+    for (int c = 0; c < NTH; ++c) { bt12[c] = sBt[(12 + jl) * NTH + c]; bt16[c] = sBt[(16 + jl) * NTH + c]; }
+    double jT = sIn[VSMPC_IN_X0 + 12 + jl], jTd = sIn[VSMPC_IN_X0 + 16 + jl];
+    double fa = 0.0, fb = 0.0;   // input terms of the current throttle block
+    if (lane < NTH) {
+        sX[12 + lane] = jT;
+        sX[16 + lane] = jTd;
+    }
+    static_for<0, D::NT - 1>([&](auto bcst) __attribute__((always_inline)) {
+        constexpr int bi = decltype(bcst)::value;
+        __syncthreads();
+        if constexpr (bi < NCJ) {
+            // input terms of the jet rows in place: f = Bt v_{tb(k)} + c (the joints do not reach these rows); v: uniform
+            // addresses (LDS broadcasts), shared by the stages of a throttle block
+            static_for<0, CHJ>([&](auto ucst) __attribute__((always_inline)) {
+                constexpr int k = bi * CHJ + decltype(ucst)::value;
+                if constexpr (k < D::N) {
+                    constexpr int tb = throttle_block_of_stage<D>(k);
+                    constexpr int tb_prev = k == 0 ? -1 : throttle_block_of_stage<D>(k == 0 ? 0 : k - 1);
+                    if constexpr (tb != tb_prev) {   // the input term changes with the throttle block only
+                        constexpr int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);   // internal offset of reference block tb
+                        fa = c12;
+                        fb = c16;
+#pragma unroll
+                        for (int c = 0; c < NTH; ++c) {
+                            const double vc = sZ[D::NU + vq + c];
+                            fa = fma(bt12[c], vc, fa);
+                            fb = fma(bt16[c], vc, fb);
+                        }
+                    }
+                    const double dt = sDt[k];
+                    const double dT = fma(jon, jTd, fa);
+                    const double dTd = fma(ja, jT, fma(jb, jTd, fb));
+                    jT = fma(dt, dT, jT);
+                    jTd = fma(dt, dTd, jTd);
+                    if (lane < NTH) {
+                        sX[NX * (k + 1) + 12 + lane] = jT;
+                        sX[NX * (k + 1) + 16 + lane] = jTd;
+                    }
+                }
+            });
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3341,7 +3412,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     }
     // ---------------------------------------------------------------- P5 joints from the register-resident factor
     switch (wave) {
-        case 0: backsub_wave<D, TPW, 0, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
+        case 0:
+            if constexpr (PIPE) p5_wave0_jets<D>(smem, lane);
+            else backsub_wave<D, TPW, 0, PIPE>(acc, sW, sZ, sXinv, sU, lane);
+            break;
         case 1: backsub_wave<D, TPW, 1, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
         case 2: backsub_wave<D, TPW, 2, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
         default: backsub_wave<D, TPW, 3, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
@@ -3407,7 +3481,10 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         const int hr0m = (lane & 1) ? 9 : 3;                       // wavefront 1, lane < 2: h_lin / h_ang
         const int cg = lane / 3, cr = lane - 3 * cg;               // wavefront 2, lane < 6: (half, row)
         const int cxr = (cg ? 6 : 0) + cr, chr0 = cg ? 9 : 3, cer = (cg ? 23 : 20) + cr;
-        if (wave == 0 && lane < NTH) {
+        // (pipelined schedule: the jets ran beside P5, p5_wave0_jets; the cascade starts at the momenta)
+        constexpr bool JETS_EARLY = PIPE;
+        constexpr int JOFF = JETS_EARLY ? 0 : 1;
+        if (!JETS_EARLY && wave == 0 && lane < NTH) {
             jon = sA[(12 + lane) * NX + 16 + lane]; ja = sA[(16 + lane) * NX + 12 + lane]; jb = sA[(16 + lane) * NX + 16 + lane];
             jT = sIn[VSMPC_IN_X0 + 12 + lane]; jTd = sIn[VSMPC_IN_X0 + 16 + lane];
             sX[12 + lane] = jT;
@@ -3448,9 +3525,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 xo[(D::NXS + D::NUO) / 2 + lane] = make_double2(sV[q], sV[q + 1]);
             }
         }
-        static_for<0, NCH + 2>([&](auto scst) __attribute__((always_inline)) {
+        static_for<0, NCH + 1 + JOFF>([&](auto scst) __attribute__((always_inline)) {
             constexpr int st = decltype(scst)::value;
-            if constexpr (st < NCH) {   // jets, chunk st
+            if constexpr (!JETS_EARLY && st < NCH) {   // jets, chunk st
                 if (wave == 0 && lane < NTH) {
                     constexpr int k0 = st * CHK;
                     double fa[CHK], fb[CHK], dtk[CHK];
@@ -3474,9 +3551,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     }
                 }
             }
-            if constexpr (st >= 1 && st - 1 < NCH) {   // momenta, chunk st - 1
+            if constexpr (st >= JOFF && st - JOFF < NCH) {   // momenta, chunk st - JOFF
                 if (wave == 1) {
-                    constexpr int k0 = (st - 1) * CHK;
+                    constexpr int k0 = (st - JOFF) * CHK;
                     constexpr int kn = k0 + CHK < D::N ? CHK : D::N - k0;   // stages of this chunk
                     // forcing g_k = A_mom T_k + f_k on the six momentum rows of the chunk's stages (T_k: the previous step's jets)
                     if (lane < 6 * kn) {
@@ -3511,9 +3588,9 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     }
                 }
             }
-            if constexpr (st >= 2 && st - 2 < NCH) {   // CoM / RPY and their error integrators, chunk st - 2
+            if constexpr (st >= JOFF + 1 && st - JOFF - 1 < NCH) {   // CoM / RPY and their error integrators, chunk st - JOFF - 1
                 if (wave == 2 && lane < 6) {
-                    constexpr int k0 = (st - 2) * CHK;
+                    constexpr int k0 = (st - JOFF - 1) * CHK;
                     double hk[CHK][3], dtk[CHK];
 #pragma unroll
                     for (int u = 0; u < CHK; ++u) {
@@ -3534,7 +3611,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                     }
                 }
             }
-            if constexpr (st + 1 < NCH + 2) __syncthreads();
+            if constexpr (st + 1 < NCH + 1 + JOFF) __syncthreads();
             if constexpr (st == 0) VS_P6_TOC(1);
         });
     }
