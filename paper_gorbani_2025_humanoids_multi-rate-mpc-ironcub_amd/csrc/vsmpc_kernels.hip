@@ -3444,12 +3444,17 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c  (Bj U = R^T y in the reduced unknowns)
     // (straight-line rounds with clamped indices: the loads of all rounds are in flight together; as a loop with a per-thread
     // trip count the rounds ran one LDS round trip after the other)
+    // Pipelined schedule: only the six momentum rows are read from here (the jets formed theirs beside P5, the CoM / RPY link has
+    // constant input terms and reads c itself): 6 N elements, one round.
     {
-        constexpr int NE = NX * D::N, RND = (NE + D::BLOCK - 1) / D::BLOCK;
+        constexpr int ROWS = PIPE ? 6 : NX;
+        constexpr int NE = ROWS * D::N, RND = (NE + D::BLOCK - 1) / D::BLOCK;
 #pragma unroll
         for (int rd = 0; rd < RND; ++rd) {
-            const int e = tid + rd * D::BLOCK, ec = e < NE ? e : NE - 1;
-            const int k = ec / NX, r = ec - k * NX;
+            const int e0 = tid + rd * D::BLOCK, ec = e0 < NE ? e0 : NE - 1;
+            const int k = ec / ROWS, rr = ec - k * ROWS;
+            const int r = PIPE ? (rr < 3 ? 3 + rr : 6 + rr) : rr;   // rows 3..5, 9..11
+            const int e = NX * k + r;
             const int jb = joint_block_of_stage<D>(k);
             const int tb = throttle_block_of_stage<D>(k);
             const int vq = tb == 0 ? D::NV - 4 : 4 * (tb - 1);  // internal offset of reference block tb
@@ -3458,7 +3463,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             for (int c = 0; c < NJC; ++c) f += sBj[r * NJ + c] * sZ[NJC * jb + c];
 #pragma unroll
             for (int c = 0; c < NTH; ++c) f += sBt[r * NTH + c] * sV[vq + c];
-            if (e < NE) sF[e] = f;
+            if (e0 < NE) sF[e] = f;
         }
     }
     __syncthreads();
