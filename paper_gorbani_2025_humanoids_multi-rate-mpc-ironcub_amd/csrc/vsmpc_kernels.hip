@@ -430,16 +430,19 @@ VS_DEV void p0_joint_reduction(double* __restrict__ sm, int lane) {
     }
 }
 
-// U = W^(-1/2) H_1 ... H_6 [y; n] for one joint block (the way back from the reduced unknowns)
-template <class D>
+// U = W^(-1/2) H_1 ... H_6 [y; n] for one joint block (the way back from the reduced unknowns).  Resumable: reflectors
+// K1 - 1 down to K0; K1 = NJC loads [y; n], K0 = 0 ends with the scaling (P6 runs the first half beside its input-term pass)
+template <class D, int K1 = NJC, int K0 = 0>
 VS_DEV void joint_expand(const double* __restrict__ sQR, const double* __restrict__ y, double (&u)[8]) {
     using S = Smem<D>;
+    if constexpr (K1 == NJC) {
 #pragma unroll
-    for (int i = 0; i < NJC; ++i) u[i] = y[i];
-    u[6] = sQR[S::QR_NS + 0];
-    u[7] = sQR[S::QR_NS + 1];
+        for (int i = 0; i < NJC; ++i) u[i] = y[i];
+        u[6] = sQR[S::QR_NS + 0];
+        u[7] = sQR[S::QR_NS + 1];
+    }
 #pragma unroll
-    for (int k = NJC - 1; k >= 0; --k) {
+    for (int k = K1 - 1; k >= K0; --k) {
         double t = 0.0;
 #pragma unroll
         for (int i = k; i < 8; ++i) t = fma(sQR[S::QR_V + 8 * k + i], u[i], t);   // uniform addresses: LDS broadcasts
@@ -447,8 +450,10 @@ VS_DEV void joint_expand(const double* __restrict__ sQR, const double* __restric
 #pragma unroll
         for (int i = k; i < 8; ++i) u[i] = fma(-t, sQR[S::QR_V + 8 * k + i], u[i]);
     }
+    if constexpr (K0 == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] *= sQR[S::QR_ISW + i];
+        for (int i = 0; i < 8; ++i) u[i] *= sQR[S::QR_ISW + i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3441,6 +3446,11 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
     double* fmout = ka->fmout;
     int* status_out = ka->status_out;
     int* iters_out = ka->iters_out;
+    // wavefront 3 has no element of the input-term pass below (pipelined schedule: 6 N of them): it starts taking the reduced joint
+    // unknowns back to joint increments here -- the first three reflectors; the rest beside the first pipeline step
+    double u8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    constexpr int JX_SPLIT = PIPE ? 3 : NJC;
+    if (PIPE && wave == 3 && lane < D::HC) joint_expand<D, NJC, JX_SPLIT>(smem + S::oQR, sZ + NJC * lane, u8);
     // input terms of every stage in parallel: f_k = Bj U_{jb(k)} + Bt v_{tb(k)} + c  (Bj U = R^T y in the reduced unknowns)
     // (straight-line rounds with clamped indices: the loads of all rounds are in flight together; as a loop with a per-thread
     // trip count the rounds ran one LDS round trip after the other)
@@ -3515,8 +3525,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // U_i = W^(-1/2) (Q y_i + N n), one block per lane, into the (dead) partial-sum array of P5
         static_assert(D::NUO <= D::NWAVES * D::NP, "joint increments fit the partial-sum array");
         if (wave == 3 && lane < D::HC) {
-            double u8[8];
-            joint_expand<D>(smem + S::oQR, sZ + NJC * lane, u8);
+            if constexpr (PIPE) joint_expand<D, JX_SPLIT, 0>(smem + S::oQR, sZ + NJC * lane, u8);
+            else joint_expand<D>(smem + S::oQR, sZ + NJC * lane, u8);
 #pragma unroll
             for (int i = 0; i < 8; ++i) sU[NJ * lane + i] = u8[i];
         }
