@@ -3540,6 +3540,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                 xo[(D::NXS + D::NUO) / 2 + lane] = make_double2(sV[q], sV[q + 1]);
             }
         }
+
         static_for<0, NCH + 1 + JOFF>([&](auto scst) __attribute__((always_inline)) {
             constexpr int st = decltype(scst)::value;
             if constexpr (!JETS_EARLY && st < NCH) {   // jets, chunk st
@@ -3564,6 +3565,19 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
                             sX[NX * (k0 + u + 1) + 16 + lane] = jTd;
                         }
                     }
+                }
+            }
+            // pipelined schedule: wavefront 3 sends the first-move block beside the second step -- everything in it is known (the
+            // jets' node 1 since P5), and its throttle percentages cost a square root that has no business on the kernel's last stretch
+            if constexpr (PIPE && st == 1) {
+                if (wave == 3 && fmout != nullptr && lane < VSMPC_FM_SIZE) {
+                    double v;
+                    if (lane < 8) v = sU[lane];                                        // delta q           (variableSamplingMPC.cpp:99)
+                    else if (lane < 12) v = sV[D::NV - 4 + (lane - 8)];                // v0                (:100)
+                    else if (lane < 16) v = Jet::throttle_of_v(sV[D::NV - 4 + (lane - 12)]);  // throttle % (:146-149)
+                    else if (lane < 20) v = sX[NX + 12 + (lane - 16)];                 // thrust, node 1    (:101)
+                    else v = sX[NX + 16 + (lane - 20)];                                // thrust rate, node 1 (:102)
+                    fmout[size_t(inst) * VSMPC_FM_SIZE + lane] = v;
                 }
             }
             if constexpr (st >= JOFF && st - JOFF < NCH) {   // momenta, chunk st - JOFF
@@ -3640,7 +3654,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         for (int i = tid; i < D::NXS / 2; i += D::BLOCK) xo[i] = make_double2(sX[2 * i], sX[2 * i + 1]);
         // (the joint increments and the throttles left from wavefront 3 during the cascade)
     }
-    if (fmout != nullptr && tid < VSMPC_FM_SIZE) {
+    if (!PIPE && fmout != nullptr && tid < VSMPC_FM_SIZE) {   // (pipelined schedule: sent by wavefront 3 during the cascade)
         double v;
         if (tid < 8) v = sU[tid];                                        // delta q           (variableSamplingMPC.cpp:99)
         else if (tid < 12) v = sV[D::NV - 4 + (tid - 8)];                // v0                (:100)
