@@ -1402,9 +1402,16 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
 template <class D>
 VS_DEV void p5_wave0_jets(double* __restrict__ smem, int lane) {
     using S = Smem<D>;
-    // stages per barrier interval: spread over all NT - 1 of them, so that no barrier of P5 waits for this wavefront
-    constexpr int CHJ = (D::N + D::NT - 2) / (D::NT - 1), NCJ = (D::N + CHJ - 1) / CHJ;
-    static_assert(NCJ <= D::NT - 1, "the jets fit the barrier intervals of P5");
+    // Stages per barrier interval: none beside the corner tile rows (the other wavefronts' steps are short there: measured, a chunk
+    // in those intervals delays their barrier), the rest spread over the joint tile rows' intervals (steps of ~0.9 k cycles).
+    // Measured: 3 stages in every interval P5 6.1 k cycles, 6 in the first three 6.8 k, 9 in the first two 7.2 k (5.5 k without).
+    constexpr int BI0 = D::NT - D::PVT;                    // first interval that gets a chunk
+    constexpr int NIV = D::NT - 1 - BI0;                   // intervals with a chunk
+#ifndef VS_P5_CHJ
+#define VS_P5_CHJ ((D::N + NIV - 1) / NIV)
+#endif
+    constexpr int CHJ = VS_P5_CHJ, NCJ = (D::N + CHJ - 1) / CHJ;
+    static_assert(NIV >= 1 && NCJ <= NIV, "the jets fit the barrier intervals of P5");
     const double* sIn = smem + S::oIn;
     const double* sA = smem + S::oA;
     const double* sBt = smem + S::oBt;
@@ -1429,11 +1436,11 @@ VS_DEV void p5_wave0_jets(double* __restrict__ smem, int lane) {
     static_for<0, D::NT - 1>([&](auto bcst) __attribute__((always_inline)) {
         constexpr int bi = decltype(bcst)::value;
         __syncthreads();
-        if constexpr (bi < NCJ) {
+        if constexpr (bi >= BI0 && bi - BI0 < NCJ) {
             // input terms of the jet rows in place: f = Bt v_{tb(k)} + c (the joints do not reach these rows); v: uniform
             // addresses (LDS broadcasts), shared by the stages of a throttle block
             static_for<0, CHJ>([&](auto ucst) __attribute__((always_inline)) {
-                constexpr int k = bi * CHJ + decltype(ucst)::value;
+                constexpr int k = (bi - BI0) * CHJ + decltype(ucst)::value;
                 if constexpr (k < D::N) {
                     constexpr int tb = throttle_block_of_stage<D>(k);
                     constexpr int tb_prev = k == 0 ? -1 : throttle_block_of_stage<D>(k == 0 ? 0 : k - 1);
