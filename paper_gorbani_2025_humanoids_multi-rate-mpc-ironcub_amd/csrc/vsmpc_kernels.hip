@@ -31,6 +31,7 @@
 //                  on the Schur complement otherwise, small systems in registers   (constraintsVSMPC.cpp:338-365)
 //   P5 back-subst  joints from the register-resident factor, tile row by tile row: z_r = X_r^T (w_r - u_r), then every
 //                  wavefront adds L_rq^T z_r of the tiles it owns to its partial sums u_q
+//                  (pipelined schedule: the panel wavefront, which holds no tile, runs the jets link of P6 beside it)
 //   P6 simulate    state trajectory, primal in the reference variable order, first-move block
 //                                                            (variableSamplingMPC.cpp:93-108,138-151)
 //
