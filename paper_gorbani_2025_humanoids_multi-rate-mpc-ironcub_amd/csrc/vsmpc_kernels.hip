@@ -2842,26 +2842,49 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             }
         }
         for (int k = lane; k < D::N; k += 64) sJetT[ZROW * D::N + k] = 0.0;
-    }
-    __syncthreads();   // ends P0 and the jet trajectories
-    if constexpr (FORM == 1) {
-        for (int e = tid; e < S::sizeZero; e += D::BLOCK) smem[S::oSZero + e] = 0.0;
-        if constexpr (D::STRUCT_LONG)   // the chains ADD into sAc
-            for (int e = tid; e < S::sizeAc; e += D::BLOCK) smem[S::oSAc + e] = 0.0;
-        for (int e = tid; e < 12 * D::NREF; e += D::BLOCK) {   // reference window + c_e on the CoM / RPY rows
-            const int row = e % 12;
-            const double off = row < 3 ? sC[20 + row] : ((row >= 6 && row < 9) ? sC[23 + row - 6] : 0.0);
-            smem[S::oSRefC + e] = sIn[VSMPC_IN_XREF + e] + off;
+        if constexpr (FORM == 1) {
+            // P1s: the affine column's whole momentum forcing A_mom Tbar_k + c_h, straight behind the trajectories it reads (same
+            // wavefront: LDS operations stay in order) and from the record instead of the linearisation the other wavefronts
+            // are still writing -- A_mom as p0_linearize copies it, c_h = alpha m R^T g as it forms it -- so that P0 needs no
+            // second block behind a second barrier (v30; was: all threads, after the barrier below, then another one)
+            const double am = sIn[VSMPC_IN_ALPHA] * sIn[VSMPC_IN_MASS];
+            const double* R = sIn + VSMPC_IN_WRB;
+            const double* gr = sIn + VSMPC_IN_GRAV;
+            for (int e = lane; e < 6 * D::N; e += 64) {
+                const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3;
+                double g = 0.0;
+#pragma unroll
+                for (int c = 0; c < NTH; ++c) g = fma(sIn[VSMPC_IN_AMOM + (3 * h + r) * NTH + c], sJetT[(D::NV + c) * D::N + k], g);
+                const double ch = h == 0 ? am * (R[0 + r] * gr[0] + R[3 + r] * gr[1] + R[6 + r] * gr[2]) : 0.0;
+                sGA[e] = g + ch;
+            }
         }
     }
-    for (int e = tid; e < 6 * D::N; e += D::BLOCK) {
-        const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3, row = (h ? 9 : 3) + r;
-        double g = 0.0;
-#pragma unroll
-        for (int c = 0; c < NTH; ++c) g = fma(sA[row * NX + 12 + c], sJetT[(D::NV + c) * D::N + k], g);
-        sGA[e] = FORM == 1 ? g + sC[row] : g;   // P1s: the affine column's whole momentum forcing A_mom Tbar_k + c_h
+    if constexpr (FORM == 1) {
+        // the zeros and the reference window (+ c_e = -p_ref / -rpy_init on the CoM / RPY rows, as p0_linearize writes it) by the
+        // wavefront whose lane 0 does the scalar CoM / gravity piece of the linearisation: none of it waits for anything
+        if (wave == 2) {
+            for (int e = lane; e < S::sizeZero; e += 64) smem[S::oSZero + e] = 0.0;
+            if constexpr (D::STRUCT_LONG)   // the chains ADD into sAc
+                for (int e = lane; e < S::sizeAc; e += 64) smem[S::oSAc + e] = 0.0;
+            for (int e = lane; e < 12 * D::NREF; e += 64) {
+                const int row = e % 12;
+                const double off = row < 3 ? -sIn[VSMPC_IN_PREF + row] : ((row >= 6 && row < 9) ? -sIn[VSMPC_IN_RPYINIT + row - 6] : 0.0);
+                smem[S::oSRefC + e] = sIn[VSMPC_IN_XREF + e] + off;
+            }
+        }
     }
-    __syncthreads();
+    __syncthreads();   // ends P0 and the jet trajectories
+    if constexpr (FORM != 1) {
+        for (int e = tid; e < 6 * D::N; e += D::BLOCK) {
+            const int h = e / (3 * D::N), k = (e / 3) % D::N, r = e % 3, row = (h ? 9 : 3) + r;
+            double g = 0.0;
+#pragma unroll
+            for (int c = 0; c < NTH; ++c) g = fma(sA[row * NX + 12 + c], sJetT[(D::NV + c) * D::N + k], g);
+            sGA[e] = g;
+        }
+        __syncthreads();
+    }
 
     VS_STAMP(1);
     VS_REFRESH_IDS();
