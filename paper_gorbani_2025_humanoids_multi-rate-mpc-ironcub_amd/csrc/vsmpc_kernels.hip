@@ -3364,7 +3364,8 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
             for (int i = 0; i < 16; ++i) z6 = fma(x6[i], readlane_f64(w6, i), z6);
             if (lane < 16) { sZ[gj] = z; sZ[16 * PV + j] = z6; }
         }
-        __syncthreads();
+        // (no barrier here: the only reader of these throttles before the next barrier is the violation check below, in this
+        // same wavefront -- LDS operations of one wavefront execute in order)
     } else if constexpr (S::DUAL3) {
         // three throttle tile rows.  Wavefront 1 forms the inverse of the last corner diagonal tile for the box QP beside
         // wavefront 0's sweep (see cholesky_wave for the second one), a few rows in front of every step so that no barrier
