@@ -2865,14 +2865,15 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         // wavefront whose lane 0 does the scalar CoM / gravity piece of the linearisation: none of it waits for anything
         if (wave == 2) {
             for (int e = lane; e < S::sizeZero; e += 64) smem[S::oSZero + e] = 0.0;
-            if constexpr (D::STRUCT_LONG)   // the chains ADD into sAc
-                for (int e = lane; e < S::sizeAc; e += 64) smem[S::oSAc + e] = 0.0;
             for (int e = lane; e < 12 * D::NREF; e += 64) {
                 const int row = e % 12;
                 const double off = row < 3 ? -sIn[VSMPC_IN_PREF + row] : ((row >= 6 && row < 9) ? -sIn[VSMPC_IN_RPYINIT + row - 6] : 0.0);
                 smem[S::oSRefC + e] = sIn[VSMPC_IN_XREF + e] + off;
             }
         }
+    }
+    if constexpr (FORM == 1 && D::STRUCT_LONG) {   // the chains ADD into sAc (30 KB at the 2x horizon: all threads)
+        for (int e = tid; e < S::sizeAc; e += D::BLOCK) smem[S::oSAc + e] = 0.0;
     }
     __syncthreads();   // ends P0 and the jet trajectories
     if constexpr (FORM != 1) {
