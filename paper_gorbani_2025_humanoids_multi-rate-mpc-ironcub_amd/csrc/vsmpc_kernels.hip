@@ -1878,11 +1878,22 @@ VS_DEV void box_qp(int n_violated, bool hold, int wave) {
             }
             __syncthreads();
         }
-        if (wave == 0) {
-            static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
-            const XTiles<D> xa{sXinv + PV * D::TS, sQP + D::NV * (D::NV + 1)};   // rows 16.. of X behind the copy of P_AA
-            dual_active_set<D>(xa, hold, lane, sSv, sQP, sSvec, sVprev, sCfg, sZ, sFlags);
+        static_assert(D::NU % 16 == 0 && D::NV > 16 && D::NV <= 32, "throttle block: tile aligned, two tile rows");
+        const XTiles<D> xa{sXinv + PV * D::TS, sQP + D::NV * (D::NV + 1)};   // rows 16.. of X behind the copy of P_AA
+        // Many violated bounds (the take-off instances enter with ten to sixteen): all columns of P up front, by all four
+        // wavefronts -- 2.25 of them per thread, ~1 k cycles -- instead of one by one in the wavefront that iterates (~0.43 k each:
+        // profiles/r04_v27_qp_dist_paper.txt, 24.6 k cycles for a two-iteration solve).  Same expression, same sums.
+        const bool all_cols = n_violated > 4;   // workgroup-uniform
+        if (all_cols) {
+            const int n = hold ? D::NV - 4 : D::NV;
+            for (int e = tid; e < D::NV * D::NV; e += D::BLOCK) {
+                const int b = e / D::NV, r = e - b * D::NV;
+                sSv[b * (D::NV + 1) + r] = xa.pcol(b, r, n);
+            }
+            __syncthreads();
         }
+        if (wave == 0)
+            dual_active_set<D>(xa, hold, lane, sSv, sQP, sSvec, sVprev, sCfg, sZ, sFlags, all_cols ? ((1ull << D::NV) - 1ull) : 0ull);
        }
       } else if (few && DUAL3) {
        if constexpr (DUAL3) {
