@@ -1387,15 +1387,16 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
             if (r - 1 < PVT) {
                 const double usum = row_sum4(up[r - 1]);
                 if (lane < 16) myU[16 * (r - 1) + j] = usum;
+                __syncthreads();   // (a step that publishes nothing -- the corner tile rows above the first joint row -- needs none:
+                                   // PVT barriers in all, which p5_wave0_jets matches)
             }
-            __syncthreads();
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // P5, wavefront 0 of the pipelined schedule (kernel v29).  It holds no tile, so the back-substitution has nothing for it to do
-// but meet its NT - 1 barriers -- and the first link of P6's cascade, the jets, depends on the throttles only, which are final
+// but meet its barriers -- and the first link of P6's cascade, the jets, depends on the throttles only, which are final
 // since P4: their input terms and their whole two-state recursion (systemDynamicsVSMPC.cpp:384-429) run here, beside P5,
 // CHJ stages per barrier interval.  P6 then starts at the momenta, one pipeline step shorter.  (Wavefront 0's slot of the
 // partial sums is zeroed once; wavefront 1 stores z.)
@@ -1403,11 +1404,12 @@ VS_DEV void backsub_wave(const d4 (&acc)[TPW], const double* __restrict__ sW, do
 template <class D>
 VS_DEV void p5_wave0_jets(double* __restrict__ smem, int lane) {
     using S = Smem<D>;
-    // Stages per barrier interval: none beside the corner tile rows (the other wavefronts' steps are short there: measured, a chunk
-    // in those intervals delays their barrier), the rest spread over the joint tile rows' intervals (steps of ~0.9 k cycles).
-    // Measured: 3 stages in every interval P5 6.1 k cycles, 6 in the first three 6.8 k, 9 in the first two 7.2 k (5.5 k without).
-    constexpr int BI0 = D::NT - D::PVT;                    // first interval that gets a chunk
-    constexpr int NIV = D::NT - 1 - BI0;                   // intervals with a chunk
+    // Stages per barrier interval.  P5 has one barrier per joint tile row (PVT of them; the corner tile rows in front publish
+    // nothing and have none): a chunk behind every barrier but the last, beside the other wavefronts' joint-row steps (~0.9 k
+    // cycles each).  Measured (when the corner rows still had barriers): 3 stages in every interval P5 6.1 k cycles, 6 in the
+    // first three 6.8 k, 9 in the first two 7.2 k (5.5 k without the jets); chunks beside the short corner-row steps delay them.
+    constexpr int BI0 = 0;                                 // first interval that gets a chunk
+    constexpr int NIV = D::PVT - 1;                        // intervals with a chunk
 #ifndef VS_P5_CHJ
 #define VS_P5_CHJ ((D::N + NIV - 1) / NIV)
 #endif
@@ -1434,7 +1436,7 @@ VS_DEV void p5_wave0_jets(double* __restrict__ smem, int lane) {
         sX[12 + lane] = jT;
         sX[16 + lane] = jTd;
     }
-    static_for<0, D::NT - 1>([&](auto bcst) __attribute__((always_inline)) {
+    static_for<0, D::PVT>([&](auto bcst) __attribute__((always_inline)) {
         constexpr int bi = decltype(bcst)::value;
         __syncthreads();
         if constexpr (bi >= BI0 && bi - BI0 < NCJ) {
