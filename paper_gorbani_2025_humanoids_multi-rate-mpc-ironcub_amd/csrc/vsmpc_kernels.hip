@@ -3471,7 +3471,7 @@ __global__ __launch_bounds__(D::BLOCK, D::WG_PER_CU) void solve_kernel(DevCfg cf
         case 2: backsub_wave<D, TPW, 2, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
         default: backsub_wave<D, TPW, 3, PIPE>(acc, sW, sZ, sXinv, sU, lane); break;
     }
-    __syncthreads();
+    // (the throttles were final before P5: their copy needs no barrier in front of it; the one behind it also covers the joints)
     if (tid < D::NV) sV[tid] = sZ[D::NU + tid];
     __syncthreads();
 
